@@ -1,0 +1,182 @@
+/*
+ * rt_api.h -- C ABI of the MI355X render path (librt_hip.so).
+ *
+ * This is the drop-in boundary for the reference's render path: the two functions of
+ * raytrace.h:9-10 (raytraceInit / raytrace), the SSBO uploads and uniform set-up behind
+ * them (raytrace.cpp:38-87), and the image ping-pong the caller performs around each
+ * dispatch (main.cpp:189-201).  No GL, no C++ types, no exceptions: plain pointers and
+ * sizes in, int status out (0 = RT_OK), message through rt_last_error().
+ *
+ * Conventions
+ *   - A context belongs to one GPU and is used from one host thread at a time.  All work
+ *     is issued on the context's stream (its own by default, rt_set_stream() to share the
+ *     caller's).  Entry points taking device pointers are asynchronous on that stream;
+ *     entry points taking host pointers return after the data is valid.
+ *   - Framebuffers are W*H*4 floats, linear RGBA32F, row 0 = BOTTOM row of the picture
+ *     (GL image coordinates, raytrace.glsl:282,294), value = running mean over frames,
+ *     alpha = (1 + rays_per_pixel) / rays_per_pixel (raytrace.glsl:289-293).
+ *   - "frame" = one dispatch of the reference = rays_per_pixel samples per pixel seeded
+ *     with pixelIndex + frameCount*745621 (raytrace.glsl:277).  N spp of the shipped
+ *     constants (RAYS_PER_PIXEL = 1) = frames 0..N-1.
+ *   - Results are bit-identical to the CPU oracle built on include/rt_math.h.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_EINVAL (-1)    /* bad argument or malformed scene */
+#define RT_EDEVICE (-2)   /* HIP runtime error (message has the HIP error string) */
+#define RT_ENOSCENE (-3)  /* render requested before rt_upload_scene */
+#define RT_ELIMIT (-4)    /* size beyond a documented limit */
+
+/* render modes, constants.h:16-19 */
+#define RT_MODE_RENDER 1
+#define RT_MODE_TRIANGLE_TESTS 2
+#define RT_MODE_BOX_TESTS 3
+#define RT_MODE_REFLECTIONS 4
+
+/* rt_params.flags */
+#define RT_FLAG_FIX_INVDIR 0x1u   /* refresh ray.invDir after each bounce (the reference never does,
+                                     raytrace.glsl:247-254,288); OFF = bug-compatible default */
+#define RT_FLAG_SUM 0x2u          /* framebuffer receives the plain SUM of the frames' colours instead of
+                                     the running mean (for sample-partitioned multi-GPU rendering) */
+#define RT_FLAG_MEGAKERNEL 0x4u   /* one thread follows one pixel's whole path (the reference's dispatch
+                                     shape) instead of the wavefront generate/extend/shade pipeline */
+#define RT_FLAG_COUNTERS 0x8u     /* also accumulate the work counters read by rt_counters() */
+
+/* Scene in the layout the reference uploads (raytrace.cpp:38-54, scene-loader.h:7-15):
+ *   nodes    num_nodes x 12 floats, AlignedMat3 {min.xyz,_}{max.xyz,_}{isLeaf,a,b,_};
+ *            leaf iff |isLeaf-1| <= 1e-4, a..b inclusive triangle range, else child ids
+ *            (raytrace.glsl:155-168); node 0 is the root
+ *   triv0/1/2  num_tris x 4 floats (xyz + pad), the three vertices of each triangle
+ *   colours  num_tris x 4 floats (rgb + pad), the per-triangle albedo of raytrace.cpp:44-52
+ * All host pointers; rt_upload_scene copies. */
+typedef struct rt_scene {
+    int32_t num_nodes;
+    int32_t num_tris;
+    const float* nodes;
+    const float* triv0;
+    const float* triv1;
+    const float* triv2;
+    const float* colours;
+} rt_scene;
+
+/* Per-frame uniforms cameraPos / cameraRotation (raytrace.cpp:80-83) and the static
+ * u_FOV / u_ViewportDist (raytrace.cpp:69-71).  rot is column-major (GLM order). */
+typedef struct rt_camera {
+    float pos[3];
+    float rot[9];
+    float fov_rad;        /* reference: (float)(90 * pi / 180) */
+    float viewport_dist;  /* reference: 0.1 */
+} rt_camera;
+
+/* u_ScreenWidth/Height, u_RaysPerPixel, u_RayBounces, renderMode, frameCount
+ * (raytrace.cpp:65-73,84-85; defaults constants.h:21-24). */
+typedef struct rt_params {
+    int32_t width;
+    int32_t height;
+    uint32_t rays_per_pixel;  /* 1 */
+    uint32_t ray_bounces;     /* 100 */
+    uint32_t render_mode;     /* RT_MODE_RENDER */
+    uint32_t frame_base;      /* frameCount of the first frame rendered */
+    uint32_t frames;          /* number of frames (= spp at rays_per_pixel 1) */
+    uint32_t frame_stride;    /* frameCount step between frames; 0 or 1 = consecutive */
+    uint32_t flags;           /* RT_FLAG_* */
+    uint32_t reserved;
+} rt_params;
+
+typedef struct rt_context rt_context;
+
+/* Number of uint64 words rt_counters() writes:
+ * [0] box tests (numBoxTests, raytrace.glsl:114)   [1] triangle tests (numTriangleTests, :80)
+ * [2] rays = calls of getHitInfo (:245)            [3] rays that hit a triangle
+ * [4] node pops that reached the node fetch (:154) [5] pixel samples (paths) */
+#define RT_NUM_COUNTERS 6
+
+/* ---- life cycle -------------------------------------------------------------------- */
+/* Creates a context on HIP device `device_id` (the GL context + compiled program of
+ * raytraceInit, raytrace.cpp:59-62). */
+int rt_create(int device_id, rt_context** out_ctx);
+int rt_destroy(rt_context* ctx);
+/* Last error message of this context ("" if none); valid until the next call on ctx.
+ * With ctx == NULL returns the message of the last failed rt_create of this thread. */
+const char* rt_last_error(const rt_context* ctx);
+/* Use the caller's hipStream_t (passed as void*) for all subsequent work; NULL restores
+ * the context's own stream. */
+int rt_set_stream(rt_context* ctx, void* hip_stream);
+/* Blocks until all work issued on the context's stream has finished. */
+int rt_synchronize(rt_context* ctx);
+
+/* ---- scene ------------------------------------------------------------------------- */
+/* initBuffers (raytrace.cpp:38-57): validates and copies the scene, re-lays it out for the
+ * device, and runs the triangle-normal kernel (shaders/normals.glsl:13-19). */
+int rt_upload_scene(rt_context* ctx, const rt_scene* scene);
+/* Copies the device-computed normals back (num_tris x 4 floats, stride of the std430 vec3[]
+ * buffer, raytrace.glsl:33-35). */
+int rt_get_normals(rt_context* ctx, float* out_normals);
+
+/* ---- rendering --------------------------------------------------------------------- */
+/* One dispatch of the reference: raytrace(cameraPos, cameraRotation, renderMode, frameCount,
+ * ...) (raytrace.h:10) with image unit 6 = d_prev_frame (read) and unit 5 = d_out_frame
+ * (written) (main.cpp:189-192).  Both are DEVICE pointers to W*H*4 floats and may alias.
+ * d_prev_frame may be NULL when frame_count == 0 (treated as zeros).  Uses params->width,
+ * height, rays_per_pixel, ray_bounces, render_mode, flags; asynchronous. */
+int rt_raytrace_frame(rt_context* ctx, const rt_camera* cam, const rt_params* params,
+                      uint32_t frame_count, const float* d_prev_frame, float* d_out_frame);
+
+/* render(scene, camera, spp) -> framebuffer: params->frames consecutive dispatches starting
+ * at frame_base, accumulated in place in d_accum (DEVICE pointer, W*H*4 floats).  With
+ * frame_base == 0 the previous content of d_accum is ignored; otherwise it must hold the
+ * running mean (or, with RT_FLAG_SUM, the sum) of the earlier frames.  Asynchronous. */
+int rt_render_device(rt_context* ctx, const rt_camera* cam, const rt_params* params, float* d_accum);
+
+/* Same with a HOST framebuffer: uploads it when frame_base != 0, renders, downloads,
+ * synchronises. */
+int rt_render(rt_context* ctx, const rt_camera* cam, const rt_params* params, float* out_rgba);
+
+/* Parity hook: closest hit of every pixel's primary ray.  ids = index into the uploaded
+ * triangle arrays or -1, t = hit distance or +inf.  HOST pointers, width*height entries,
+ * row 0 = bottom. */
+int rt_primary_hits(rt_context* ctx, const rt_camera* cam, int32_t width, int32_t height,
+                    int32_t* out_ids, float* out_t);
+
+/* Work counters accumulated by renders issued with RT_FLAG_COUNTERS since the last
+ * rt_reset_counters(); synchronises the stream. */
+int rt_counters(rt_context* ctx, uint64_t out[RT_NUM_COUNTERS]);
+int rt_reset_counters(rt_context* ctx);
+
+/* ---- instrumentation --------------------------------------------------------------- */
+/* Kernel classes reported by rt_kernel_times(). */
+#define RT_K_GENERATE 0
+#define RT_K_EXTEND 1
+#define RT_K_SHADE 2
+#define RT_K_TAIL 3
+#define RT_K_ACCUMULATE 4
+#define RT_K_MEGA 5
+#define RT_NUM_KERNEL_CLASSES 6
+/* enable != 0: bracket every kernel launch with HIP events on the context's stream (adds
+ * event overhead; keep it off in throughput runs).  rt_kernel_times synchronises and
+ * returns the summed milliseconds and launch counts per class since profiling was enabled
+ * or last read, then clears them. */
+int rt_set_profiling(rt_context* ctx, int enable);
+int rt_kernel_times(rt_context* ctx, float out_ms[RT_NUM_KERNEL_CLASSES],
+                    uint32_t out_launches[RT_NUM_KERNEL_CLASSES]);
+
+/* Evaluates the shared math of include/rt_math.h ON THE DEVICE for n inputs (host pointers):
+ * out[0..n) = log(x), out[n..2n) = cos(x), out[2n..3n) = exp(x), out[3n..4n) = sqrt(x),
+ * out[4n..5n) = 1/x, out[5n..6n) = pow(x, 0.35).  Lets tests compare device and host bit for bit. */
+int rt_selftest_math(rt_context* ctx, const float* x, int32_t n, float* out);
+
+/* Library build identification, e.g. "rt_hip gfx950 <date>". */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */
