@@ -1,0 +1,903 @@
+// librt_hip.so -- the render path on MI355X (gfx950): kernels + the C ABI of include/rt_api.h.
+//
+// Two pipelines produce identical pixels:
+//   wavefront (default)  generate -> [extend -> shade(+compact)] x RT_WF_BOUNCES -> tail
+//       generate   one primary ray per pixel into a ray queue, 8x8 pixel squares per wave
+//       extend     closest hit of every ray of a queue (BVH traversal + triangle tests)
+//       shade      consumes the hits: sky + framebuffer accumulation for finished paths, diffuse
+//                  bounce + Russian roulette for the others, survivors compacted into the next queue
+//                  with a wave ballot, an mbcnt prefix and ONE atomic per wave
+//       tail       the few paths still alive after RT_WF_BOUNCES bounces are finished by one launch
+//                  in which each lane loops extend+shade, so the launch count per frame is fixed and
+//                  the host never reads a queue size back
+//   megakernel (RT_FLAG_MEGAKERNEL, debug render modes, rays_per_pixel > 1)
+//       one lane follows one pixel's whole sample loop, the reference's dispatch shape
+//       (raytrace.glsl:272-305).
+// There is no CPU fallback: without a GPU rt_create fails.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_api.h"
+#include "rt_device.h"
+
+#define RT_WF_BOUNCES 2       // bounces handled by wavefront kernels before the tail launch
+#define RT_TAIL_BLOCKS 1024   // grid of the tail kernel (grid-stride)
+#define RT_MAX_DEPTH 126      // deepest tree accepted (the reference's own stack holds 128 entries)
+
+// ------------------------------------------------------------------------------------------------
+// device structures
+// ------------------------------------------------------------------------------------------------
+struct DQueue {
+    float4* o;    // origin.xyz, w = pixel index bits (0xffffffff: slot holds no ray)
+    float4* d;    // dir.xyz,    w = RNG seed bits
+    float4* inv;  // invDir.xyz (the primary ray's unless RT_FLAG_FIX_INVDIR)
+    float4* thr;  // throughput rgb
+};
+
+struct FrameArgs {
+    uint32_t frame;       // frameCount of this dispatch
+    uint32_t bounces;     // u_RayBounces
+    uint32_t rpp;         // u_RaysPerPixel
+    uint32_t mode;        // renderMode
+    uint32_t sum_mode;    // RT_FLAG_SUM
+    uint32_t read_prev;   // 0: treat the previous frame as zeros
+    int tiles_x, num_tiles;
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+
+// shaders/normals.glsl:13-19, one lane per triangle; also stores the colour next to the normal.
+__global__ __launch_bounds__(RT_BLOCK) void k_normals(const float4* v0, const float4* v1, const float4* v2,
+                                                      const float4* colours, float4* shade, int n) {
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 a = v0[i], b = v1[i], c = v2[i];
+    rt_vec3 A = rt_v3(a.x, a.y, a.z), B = rt_v3(b.x, b.y, b.z), Cc = rt_v3(c.x, c.y, c.z);
+    rt_vec3 nrm = rt_normalize(rt_cross(rt_sub(A, B), rt_sub(A, Cc)));
+    shade[2 * (size_t)i] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+    float4 col = colours[i];
+    shade[2 * (size_t)i + 1] = make_float4(col.x, col.y, col.z, 0.0f);
+}
+
+__device__ __forceinline__ void flush_counters(const Counters& cn, unsigned long long paths, unsigned long long* g) {
+    // per-wave sums, then one atomic per counter per wave
+    unsigned long long v[RT_NUM_COUNTERS] = {cn.box, cn.tri, cn.rays, cn.hits, cn.pops, paths};
+#pragma unroll
+    for (int k = 0; k < RT_NUM_COUNTERS; k++) {
+        unsigned long long x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&g[k], x);
+    }
+}
+
+__device__ __forceinline__ Stack make_stack(uint2 (*s_stack)[RT_BLOCK], uint2* spill, size_t spill_stride, size_t slot) {
+    Stack st;
+    st.lds = &s_stack[0][threadIdx.x];
+    st.spill = spill ? spill + slot : nullptr;
+    st.spill_stride = spill_stride;
+    return st;
+}
+
+__device__ __forceinline__ void store_pixel(const FrameArgs& fa, const float4* prev, float4* out, size_t at, float r,
+                                            float g, float b, float a) {
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (fa.read_prev) acc = prev[at];
+    float fc = (float)fa.frame, fc1 = (float)(fa.frame + 1u);
+    bool s = fa.sum_mode != 0;
+    out[at] = make_float4(accumulate(acc.x, r, fc, fc1, s), accumulate(acc.y, g, fc, fc1, s),
+                          accumulate(acc.z, b, fc, fc1, s), accumulate(acc.w, a, fc, fc1, s));
+}
+
+// ---- megakernel ----------------------------------------------------------------------------------
+template <bool COUNT, bool FIX>
+__global__ __launch_bounds__(RT_BLOCK) void k_mega(DScene sc, DCamera cam, FrameArgs fa, const float4* prev, float4* out,
+                                                   unsigned long long* g_counters, uint2* spill, size_t spill_stride) {
+    __shared__ uint2 s_stack[RT_LDS_STACK][RT_BLOCK];
+    int gx, gy;
+    tile_pixel(blockIdx.x, fa.tiles_x, threadIdx.x, gx, gy);
+    bool active = gx < cam.width && gy < cam.height;
+    Counters cn = {0, 0, 0, 0, 0};
+    unsigned long long paths = 0;
+    if (active) {
+        Stack st = make_stack(s_stack, spill, spill_stride, (size_t)blockIdx.x * RT_BLOCK + threadIdx.x);
+        uint32_t reflections = 0;
+        rt_vec3 o0, d0, inv0;
+        primary_ray(cam, gx, gy, o0, d0, inv0);
+        uint32_t seed = pixel_seed(cam, gx, gy, fa.frame);
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 1.0f;
+        for (uint32_t s = 0; s < fa.rpp; s++) {
+            PathState p;
+            p.o = o0;
+            p.d = d0;
+            p.inv = inv0;
+            p.thr = rt_v3(1.0f, 1.0f, 1.0f);
+            p.seed = seed;
+            rt_vec3 result = rt_v3(0.0f, 0.0f, 0.0f);
+            for (uint32_t i = 0; i < fa.bounces; i++) {
+                float t;
+                int id;
+                closest_hit<COUNT>(sc, p.o, p.d, p.inv, st, t, id, cn);
+                if (t < RT_INF) {
+                    if (!bounce<FIX>(sc, p, t, id, i)) break;
+                } else {
+                    result = rt_add(result, rt_mul(sample_sky(p.d), p.thr));
+                    break;
+                }
+                reflections++;
+            }
+            seed = p.seed;
+            cr += result.x;
+            cg += result.y;
+            cb += result.z;
+            ca += 1.0f;
+            paths++;
+        }
+        float rpp = (float)fa.rpp;
+        cr = cr / rpp;
+        cg = cg / rpp;
+        cb = cb / rpp;
+        ca = ca / rpp;
+        size_t at = (size_t)gy * (size_t)cam.width + (size_t)gx;
+        if (fa.mode == RT_MODE_RENDER || !COUNT) {
+            store_pixel(fa, prev, out, at, cr, cg, cb, ca);
+        } else if (fa.mode == RT_MODE_TRIANGLE_TESTS) {
+            float f = (float)(cn.tri < 500u ? cn.tri : 500u) / 500.0f;
+            out[at] = make_float4(f * 1.0f, f * 1.0f, f * 0.0f, f * 0.0f);
+        } else if (fa.mode == RT_MODE_BOX_TESTS) {
+            float f = (float)(cn.box < 1000u ? cn.box : 1000u) / 1000.0f;
+            out[at] = make_float4(f * 0.0f, f * 1.0f, f * 1.0f, f * 1.0f);
+        } else {
+            uint32_t m = reflections < fa.bounces ? reflections : fa.bounces;
+            float f = (float)m / (float)fa.bounces;
+            out[at] = make_float4(f, f, f, f);
+        }
+    }
+    if (COUNT && g_counters) flush_counters(cn, paths, g_counters);
+}
+
+// ---- wavefront: generate ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(DCamera cam, FrameArgs fa, DQueue q, uint32_t* counts,
+                                                       unsigned long long* g_counters) {
+    int gx, gy;
+    tile_pixel(blockIdx.x, fa.tiles_x, threadIdx.x, gx, gy);
+    size_t slot = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot < RT_WF_BOUNCES + 2) counts[slot] = slot == 0 ? (uint32_t)fa.num_tiles * RT_BLOCK : 0u;
+    bool active = gx < cam.width && gy < cam.height;
+    rt_vec3 o = rt_v3(0, 0, 0), d = rt_v3(0, 0, 1.0f), inv = rt_v3(0, 0, 0);
+    uint32_t pix = 0xffffffffu, seed = 0;
+    if (active) {
+        primary_ray(cam, gx, gy, o, d, inv);
+        seed = pixel_seed(cam, gx, gy, fa.frame);
+        pix = (uint32_t)gy * (uint32_t)cam.width + (uint32_t)gx;
+    }
+    q.o[slot] = make_float4(o.x, o.y, o.z, rt_u2f(pix));
+    q.d[slot] = make_float4(d.x, d.y, d.z, rt_u2f(seed));
+    q.inv[slot] = make_float4(inv.x, inv.y, inv.z, 0.0f);
+    q.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    if (g_counters) {  // one path per pixel on this pipeline
+        Counters none = {0, 0, 0, 0, 0};
+        flush_counters(none, active ? 1ull : 0ull, g_counters);
+    }
+}
+
+// ---- wavefront: extend -----------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene sc, DQueue q, const uint32_t* n_ptr, float2* hits,
+                                                     unsigned long long* g_counters, uint2* spill, size_t spill_stride) {
+    __shared__ uint2 s_stack[RT_LDS_STACK][RT_BLOCK];
+    uint32_t n = *n_ptr;
+    size_t slot = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if ((size_t)blockIdx.x * RT_BLOCK >= n) return;  // whole block beyond the queue
+    Counters cn = {0, 0, 0, 0, 0};
+    if (slot < n) {
+        float4 o = q.o[slot];
+        if (rt_f2u(o.w) != 0xffffffffu) {
+            float4 d = q.d[slot], inv = q.inv[slot];
+            Stack st = make_stack(s_stack, spill, spill_stride, slot);
+            float t;
+            int id;
+            closest_hit<COUNT>(sc, rt_v3(o.x, o.y, o.z), rt_v3(d.x, d.y, d.z), rt_v3(inv.x, inv.y, inv.z), st, t, id, cn);
+            hits[slot] = make_float2(t, rt_u2f((uint32_t)id));
+        }
+    }
+    if (COUNT && g_counters) flush_counters(cn, 0, g_counters);
+}
+
+// ---- wavefront: shade + compact --------------------------------------------------------------------
+template <bool FIX>
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene sc, FrameArgs fa, uint32_t bounce_index, DQueue qin,
+                                                    const uint32_t* n_in_ptr, const float2* hits, DQueue qout,
+                                                    uint32_t* n_out_ptr, const float4* prev, float4* out) {
+    uint32_t n = *n_in_ptr;
+    if ((size_t)blockIdx.x * RT_BLOCK >= n) return;
+    size_t slot = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    bool alive = false;
+    PathState p;
+    uint32_t pix = 0xffffffffu;
+    if (slot < n) {
+        float4 o = qin.o[slot];
+        pix = rt_f2u(o.w);
+        if (pix != 0xffffffffu) {
+            float4 d = qin.d[slot], inv = qin.inv[slot], thr = qin.thr[slot];
+            float2 h = hits[slot];
+            p.o = rt_v3(o.x, o.y, o.z);
+            p.d = rt_v3(d.x, d.y, d.z);
+            p.inv = rt_v3(inv.x, inv.y, inv.z);
+            p.thr = rt_v3(thr.x, thr.y, thr.z);
+            p.seed = rt_f2u(d.w);
+            rt_vec3 result = rt_v3(0.0f, 0.0f, 0.0f);
+            if (h.x < RT_INF) {
+                alive = bounce<FIX>(sc, p, h.x, (int)rt_f2u(h.y), bounce_index);
+                if (bounce_index + 1u >= fa.bounces) alive = false;  // the bounce loop is exhausted
+            } else {
+                result = rt_mul(sample_sky(p.d), p.thr);
+            }
+            if (!alive) store_pixel(fa, prev, out, (size_t)pix, result.x, result.y, result.z, 2.0f);
+        }
+    }
+    // compaction: ballot + prefix count inside the wave, one atomic per wave
+    unsigned long long mask = __ballot(alive);
+    uint32_t total = (uint32_t)__popcll(mask);
+    if (total) {
+        uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        uint32_t base = 0;
+        if (prefix == 0 && alive) base = atomicAdd(n_out_ptr, total);
+        int leader = __ffsll((long long)mask) - 1;
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (alive) {
+            size_t dst = (size_t)base + prefix;
+            qout.o[dst] = make_float4(p.o.x, p.o.y, p.o.z, rt_u2f(pix));
+            qout.d[dst] = make_float4(p.d.x, p.d.y, p.d.z, rt_u2f(p.seed));
+            qout.inv[dst] = make_float4(p.inv.x, p.inv.y, p.inv.z, 0.0f);
+            qout.thr[dst] = make_float4(p.thr.x, p.thr.y, p.thr.z, 0.0f);
+        }
+    }
+}
+
+// ---- wavefront: tail -------------------------------------------------------------------------------
+// Finishes every path of a (small) queue: each lane loops extend + shade from bounce `first_bounce`.
+template <bool COUNT, bool FIX>
+__global__ __launch_bounds__(RT_BLOCK) void k_tail(DScene sc, FrameArgs fa, uint32_t first_bounce, DQueue q,
+                                                   const uint32_t* n_ptr, const float4* prev, float4* out,
+                                                   unsigned long long* g_counters, uint2* spill, size_t spill_stride) {
+    __shared__ uint2 s_stack[RT_LDS_STACK][RT_BLOCK];
+    uint32_t n = *n_ptr;
+    Counters cn = {0, 0, 0, 0, 0};
+    size_t lane_slot = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    Stack st = make_stack(s_stack, spill, spill_stride, lane_slot);
+    for (size_t i = lane_slot; i < n; i += (size_t)gridDim.x * RT_BLOCK) {
+        float4 o = q.o[i], d = q.d[i], inv = q.inv[i], thr = q.thr[i];
+        PathState p;
+        p.o = rt_v3(o.x, o.y, o.z);
+        p.d = rt_v3(d.x, d.y, d.z);
+        p.inv = rt_v3(inv.x, inv.y, inv.z);
+        p.thr = rt_v3(thr.x, thr.y, thr.z);
+        p.seed = rt_f2u(d.w);
+        uint32_t pix = rt_f2u(o.w);
+        rt_vec3 result = rt_v3(0.0f, 0.0f, 0.0f);
+        for (uint32_t b = first_bounce; b < fa.bounces; b++) {
+            float t;
+            int id;
+            closest_hit<COUNT>(sc, p.o, p.d, p.inv, st, t, id, cn);
+            if (t < RT_INF) {
+                if (!bounce<FIX>(sc, p, t, id, b)) break;
+            } else {
+                result = rt_mul(sample_sky(p.d), p.thr);
+                break;
+            }
+        }
+        store_pixel(fa, prev, out, (size_t)pix, result.x, result.y, result.z, 2.0f);
+    }
+    if (COUNT && g_counters) flush_counters(cn, 0, g_counters);
+}
+
+// ---- parity hook: primary hits -----------------------------------------------------------------------
+__global__ __launch_bounds__(RT_BLOCK) void k_primary_hits(DScene sc, DCamera cam, int tiles_x, int* ids, float* ts,
+                                                           uint2* spill, size_t spill_stride) {
+    __shared__ uint2 s_stack[RT_LDS_STACK][RT_BLOCK];
+    int gx, gy;
+    tile_pixel(blockIdx.x, tiles_x, threadIdx.x, gx, gy);
+    if (gx >= cam.width || gy >= cam.height) return;
+    Stack st = make_stack(s_stack, spill, spill_stride, (size_t)blockIdx.x * RT_BLOCK + threadIdx.x);
+    rt_vec3 o, d, inv;
+    primary_ray(cam, gx, gy, o, d, inv);
+    Counters cn = {0, 0, 0, 0, 0};
+    float t;
+    int id;
+    closest_hit<false>(sc, o, d, inv, st, t, id, cn);
+    size_t at = (size_t)gy * (size_t)cam.width + (size_t)gx;
+    ids[at] = id;
+    ts[at] = t;
+}
+
+__global__ void k_selftest_math(const float* x, int n, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    out[i] = rt_log(v);
+    out[(size_t)n + i] = rt_cos(v);
+    out[2 * (size_t)n + i] = rt_exp(v);
+    out[3 * (size_t)n + i] = rt_sqrt(v);
+    out[4 * (size_t)n + i] = 1.0f / v;
+    out[5 * (size_t)n + i] = rt_pow(v, 0.35f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct EventPair {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct rt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    bool has_scene = false;
+    DScene sc{};
+    float4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    float4* d_shade = nullptr;
+    int num_tris = 0;
+    int max_depth = 0;
+
+    // per-resolution buffers
+    size_t cap_slots = 0;  // queue capacity (padded pixel count)
+    DQueue q[2] = {};
+    float2* d_hits = nullptr;
+    uint32_t* d_counts = nullptr;
+    uint2* d_spill = nullptr;
+    size_t spill_entries = 0;
+    float4* d_frame = nullptr;  // framebuffer for the host-pointer entry points
+    size_t frame_pixels = 0;
+
+    unsigned long long* d_counters = nullptr;
+
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> free_events;
+    double ms[RT_NUM_KERNEL_CLASSES] = {};
+    uint32_t launches[RT_NUM_KERNEL_CLASSES] = {};
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(rt_context* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                                 \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return fail(ctx, RT_EDEVICE, "%s: %s", #call, hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T>
+static void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void free_scene(rt_context* c) {
+    dfree(c->d_nodes);
+    dfree(c->d_tris);
+    dfree(c->d_shade);
+    c->has_scene = false;
+}
+
+static void free_buffers(rt_context* c) {
+    for (int k = 0; k < 2; k++) {
+        dfree(c->q[k].o);
+        dfree(c->q[k].d);
+        dfree(c->q[k].inv);
+        dfree(c->q[k].thr);
+    }
+    dfree(c->d_hits);
+    dfree(c->d_spill);
+    c->cap_slots = 0;
+    c->spill_entries = 0;
+}
+
+// Brackets one launch with events when profiling is on.
+struct LaunchTimer {
+    rt_context* c;
+    EventPair ep{};
+    bool on;
+    LaunchTimer(rt_context* ctx, int cls) : c(ctx), on(ctx->profiling) {
+        if (!on) return;
+        if (!c->free_events.empty()) {
+            ep = c->free_events.back();
+            c->free_events.pop_back();
+        } else {
+            (void)hipEventCreate(&ep.a);
+            (void)hipEventCreate(&ep.b);
+        }
+        ep.cls = cls;
+        (void)hipEventRecord(ep.a, c->stream);
+    }
+    ~LaunchTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, c->stream);
+        c->pending.push_back(ep);
+    }
+};
+
+static int ensure_buffers(rt_context* c, int width, int height) {
+    int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+    size_t slots = (size_t)tiles_x * tiles_y * RT_BLOCK;
+    size_t min_slots = (size_t)RT_TAIL_BLOCKS * RT_BLOCK;
+    if (slots < min_slots) slots = min_slots;
+    size_t want_spill = c->max_depth > RT_LDS_STACK ? (size_t)(c->max_depth - RT_LDS_STACK + 1) : 0;
+    if (slots <= c->cap_slots && want_spill <= c->spill_entries) return RT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_buffers(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(c, hipMalloc(&c->q[k].o, slots * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->q[k].d, slots * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->q[k].inv, slots * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->q[k].thr, slots * sizeof(float4)));
+    }
+    HIPCHK(c, hipMalloc(&c->d_hits, slots * sizeof(float2)));
+    if (want_spill) HIPCHK(c, hipMalloc(&c->d_spill, want_spill * slots * sizeof(uint2)));
+    c->cap_slots = slots;
+    c->spill_entries = want_spill;
+    return RT_OK;
+}
+
+static int check_render_args(rt_context* c, const rt_camera* cam, const rt_params* p) {
+    if (!c) return RT_EINVAL;
+    if (!cam || !p) return fail(c, RT_EINVAL, "camera and params must not be NULL");
+    if (!c->has_scene) return fail(c, RT_ENOSCENE, "no scene uploaded");
+    if (p->width <= 0 || p->height <= 0) return fail(c, RT_EINVAL, "width and height must be positive");
+    if ((int64_t)p->width * p->height > (int64_t)16384 * 16384)
+        return fail(c, RT_ELIMIT, "image larger than 16384x16384 pixels");
+    if (p->rays_per_pixel == 0) return fail(c, RT_EINVAL, "rays_per_pixel must be at least 1");
+    if (p->render_mode < RT_MODE_RENDER || p->render_mode > RT_MODE_REFLECTIONS)
+        return fail(c, RT_EINVAL, "render_mode must be 1..4");
+    return RT_OK;
+}
+
+static DCamera make_dcamera(const rt_camera* cam, int width, int height) {
+    DCamera d;
+    for (int k = 0; k < 3; k++) d.pos[k] = cam->pos[k];
+    for (int k = 0; k < 9; k++) d.rot[k] = cam->rot[k];
+    d.viewport_dist = cam->viewport_dist;
+    // tan(u_FOV / 2.0f) * u_ViewportDist * 2.0f / u_ScreenWidth (raytrace.glsl:279); the tangent is
+    // rounded once from double precision
+    float tan_half = (float)std::tan((double)(cam->fov_rad / 2.0f));
+    d.pixel_width = ((tan_half * cam->viewport_dist) * 2.0f) / (float)width;
+    d.width_f = (float)width;
+    d.half_w = (float)width / 2.0f;
+    d.half_h = (float)height / 2.0f;
+    d.width = width;
+    d.height = height;
+    return d;
+}
+
+extern "C" {
+
+const char* rt_version(void) { return "rt_hip gfx950 " __DATE__; }
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_create(int device_id, rt_context** out_ctx) {
+    if (!out_ctx) return fail(nullptr, RT_EINVAL, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, RT_EDEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(nullptr, RT_EINVAL, "device %d out of range [0,%d)", device_id, count);
+    rt_context* c = new rt_context();
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->own_stream)) != hipSuccess ||
+        (e = hipMalloc(&c->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&c->d_counts, 64 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long))) != hipSuccess) {
+        int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    c->stream = c->own_stream;
+    *out_ctx = c;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context* c) {
+    if (!c) return RT_EINVAL;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_buffers(c);
+    dfree(c->d_frame);
+    dfree(c->d_counters);
+    dfree(c->d_counts);
+    for (auto& ep : c->pending) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    for (auto& ep : c->free_events) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_set_stream(rt_context* c, void* hip_stream) {
+    if (!c) return RT_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+
+int rt_synchronize(rt_context* c) {
+    if (!c) return RT_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// Re-lays the reference's buffers out for the device (see rt_device.h) after validating that the node
+// array is a tree whose indices stay in range -- a malformed scene must fail here, not fault on the GPU.
+int rt_upload_scene(rt_context* c, const rt_scene* s) {
+    if (!c) return RT_EINVAL;
+    if (!s || !s->nodes || !s->triv0 || !s->triv1 || !s->triv2 || !s->colours)
+        return fail(c, RT_EINVAL, "scene pointers must not be NULL");
+    const int N = s->num_nodes, T = s->num_tris;
+    if (N < 1 || T < 1) return fail(c, RT_EINVAL, "scene needs at least one node and one triangle");
+
+    struct Item {
+        int node, depth, parent_rec, slot;
+    };
+    std::vector<float> recs;        // 16 floats per inner node
+    std::vector<float> tris;        // 12 floats per leaf-ordered triangle
+    std::vector<char> seen((size_t)N, 0);
+    std::vector<Item> todo;
+    recs.reserve((size_t)N * 8);
+    tris.reserve((size_t)T * 12);
+    int root_ref = 0, max_depth = 0;
+    auto as_f = [](int v) { return rt_u2f((uint32_t)v); };
+    todo.push_back({0, 0, -1, 0});
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (it.node < 0 || it.node >= N) return fail(c, RT_EINVAL, "node index %d out of range", it.node);
+        if (seen[it.node]) return fail(c, RT_EINVAL, "node %d is referenced twice (not a tree)", it.node);
+        seen[it.node] = 1;
+        if (it.depth > RT_MAX_DEPTH) return fail(c, RT_ELIMIT, "tree deeper than %d levels", RT_MAX_DEPTH);
+        if (it.depth > max_depth) max_depth = it.depth;
+        const float* nd = s->nodes + (size_t)12 * it.node;
+        bool leaf = std::fabs(nd[8] - 1.0f) <= RT_EPS;  // raytrace.glsl:155
+        int a = (int)nd[9], b = (int)nd[10];             // raytrace.glsl:157-158,167-168
+        int ref;
+        if (leaf) {
+            if (b < a) {
+                ref = RT_REF_EMPTY;
+            } else {
+                if (a < 0 || b >= T) return fail(c, RT_EINVAL, "leaf %d: triangle range [%d,%d] out of range", it.node, a, b);
+                ref = ~(int)(tris.size() / 12);
+                for (int k = a; k <= b; k++) {
+                    const float *p0 = s->triv0 + 4 * (size_t)k, *p1 = s->triv1 + 4 * (size_t)k, *p2 = s->triv2 + 4 * (size_t)k;
+                    float rec[12] = {p0[0], p0[1], p0[2], as_f(k == b ? 1 : 0),
+                                     p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], as_f(k),
+                                     p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f};
+                    tris.insert(tris.end(), rec, rec + 12);
+                }
+                if (tris.size() / 12 > (size_t)0x7ffffff0) return fail(c, RT_ELIMIT, "too many triangle records");
+            }
+        } else {
+            if (a < 0 || a >= N || b < 0 || b >= N) return fail(c, RT_EINVAL, "node %d: child index out of range", it.node);
+            ref = (int)(recs.size() / 16);
+            recs.resize(recs.size() + 16, 0.0f);
+            // children are expanded depth-first, first child next (keeps subtrees contiguous)
+            todo.push_back({b, it.depth + 1, ref, 1});
+            todo.push_back({a, it.depth + 1, ref, 0});
+        }
+        if (it.parent_rec < 0) {
+            root_ref = ref;
+        } else {
+            float* pr = recs.data() + (size_t)16 * it.parent_rec;
+            const float* mn = nd;
+            const float* mx = nd + 4;
+            if (it.slot == 0) {
+                pr[0] = mn[0]; pr[1] = mn[1]; pr[2] = mn[2]; pr[3] = mx[0]; pr[4] = mx[1]; pr[5] = mx[2];
+                pr[12] = as_f(ref);
+            } else {
+                pr[6] = mn[0]; pr[7] = mn[1]; pr[8] = mn[2]; pr[9] = mx[0]; pr[10] = mx[1]; pr[11] = mx[2];
+                pr[13] = as_f(ref);
+            }
+        }
+    }
+
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    size_t nrec = recs.size() / 16, ntri = tris.size() / 12;
+    HIPCHK(c, hipMalloc(&c->d_nodes, (nrec ? nrec : 1) * 16 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->d_tris, (ntri ? ntri : 1) * 12 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->d_shade, (size_t)T * 2 * sizeof(float4)));
+    if (nrec) HIPCHK(c, hipMemcpyAsync(c->d_nodes, recs.data(), nrec * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (ntri) HIPCHK(c, hipMemcpyAsync(c->d_tris, tris.data(), ntri * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    // the normals kernel reads the caller's vertex arrays as the reference's does (normals.glsl:15-17)
+    float4 *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *col = nullptr;
+    size_t vb = (size_t)T * sizeof(float4);
+    HIPCHK(c, hipMalloc(&v0, vb));
+    HIPCHK(c, hipMalloc(&v1, vb));
+    HIPCHK(c, hipMalloc(&v2, vb));
+    HIPCHK(c, hipMalloc(&col, vb));
+    HIPCHK(c, hipMemcpyAsync(v0, s->triv0, vb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(v1, s->triv1, vb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(v2, s->triv2, vb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(col, s->colours, vb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_normals, dim3((T + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, v0, v1, v2, col,
+                       c->d_shade, T);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(v0);
+    dfree(v1);
+    dfree(v2);
+    dfree(col);
+
+    c->sc.nodes = c->d_nodes;
+    c->sc.tris = c->d_tris;
+    c->sc.shade = c->d_shade;
+    for (int k = 0; k < 3; k++) {
+        c->sc.rmin[k] = s->nodes[k];
+        c->sc.rmax[k] = s->nodes[4 + k];
+    }
+    c->sc.root_ref = root_ref;
+    c->sc.num_tris = T;
+    c->num_tris = T;
+    c->max_depth = max_depth;
+    c->has_scene = true;
+    // a deeper tree may need a larger spill area: force re-allocation on the next render
+    if (c->max_depth > RT_LDS_STACK && (size_t)(c->max_depth - RT_LDS_STACK + 1) > c->spill_entries) free_buffers(c);
+    return RT_OK;
+}
+
+int rt_get_normals(rt_context* c, float* out) {
+    if (!c) return RT_EINVAL;
+    if (!out) return fail(c, RT_EINVAL, "out_normals is NULL");
+    if (!c->has_scene) return fail(c, RT_ENOSCENE, "no scene uploaded");
+    std::vector<float> tmp((size_t)c->num_tris * 8);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_shade, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->num_tris; i++) std::memcpy(out + 4 * (size_t)i, tmp.data() + 8 * (size_t)i, 4 * sizeof(float));
+    return RT_OK;
+}
+
+int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, uint32_t frame_count,
+                      const float* d_prev_frame, float* d_out_frame) {
+    int rc = check_render_args(c, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!d_out_frame) return fail(c, RT_EINVAL, "d_out_frame is NULL");
+    const bool sum = (p->flags & RT_FLAG_SUM) != 0;
+    const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    const bool mega = (p->flags & RT_FLAG_MEGAKERNEL) != 0 || p->render_mode != RT_MODE_RENDER ||
+                      p->rays_per_pixel != 1 || p->ray_bounces == 0;
+    if (!d_prev_frame && (sum || frame_count != 0)) return fail(c, RT_EINVAL, "d_prev_frame is NULL for frame %u", frame_count);
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure_buffers(c, p->width, p->height)) != RT_OK) return rc;
+
+    DCamera dc = make_dcamera(cam, p->width, p->height);
+    FrameArgs fa;
+    fa.frame = frame_count;
+    fa.bounces = p->ray_bounces;
+    fa.rpp = p->rays_per_pixel;
+    fa.mode = p->render_mode;
+    fa.sum_mode = sum ? 1u : 0u;
+    fa.read_prev = (sum || frame_count != 0) ? 1u : 0u;
+    fa.tiles_x = (p->width + 15) / 16;
+    fa.num_tiles = fa.tiles_x * ((p->height + 15) / 16);
+    const float4* prev = (const float4*)d_prev_frame;
+    float4* out = (float4*)d_out_frame;
+    unsigned long long* gcnt = count ? c->d_counters : nullptr;
+    const size_t sstride = c->cap_slots;
+    dim3 blk(RT_BLOCK), grid_px(fa.num_tiles);
+
+    if (mega) {
+        LaunchTimer lt(c, RT_K_MEGA);
+        const bool need_cnt = count || p->render_mode != RT_MODE_RENDER;
+#define MEGA(C_, F_) hipLaunchKernelGGL((k_mega<C_, F_>), grid_px, blk, 0, c->stream, c->sc, dc, fa, prev, out, gcnt, c->d_spill, sstride)
+        if (need_cnt) { if (fix) MEGA(true, true); else MEGA(true, false); }
+        else { if (fix) MEGA(false, true); else MEGA(false, false); }
+#undef MEGA
+        HIPCHK(c, hipGetLastError());
+        return RT_OK;
+    }
+
+    uint32_t* counts = c->d_counts;
+    {
+        LaunchTimer lt(c, RT_K_GENERATE);
+        hipLaunchKernelGGL(k_generate, grid_px, blk, 0, c->stream, dc, fa, c->q[0], counts, gcnt);
+    }
+    uint32_t wf = p->ray_bounces < RT_WF_BOUNCES ? p->ray_bounces : RT_WF_BOUNCES;
+    for (uint32_t b = 0; b < wf; b++) {
+        DQueue qin = c->q[b & 1], qout = c->q[(b + 1) & 1];
+        {
+            LaunchTimer lt(c, RT_K_EXTEND);
+            if (count)
+                hipLaunchKernelGGL((k_extend<true>), grid_px, blk, 0, c->stream, c->sc, qin, counts + b, c->d_hits, gcnt, c->d_spill, sstride);
+            else
+                hipLaunchKernelGGL((k_extend<false>), grid_px, blk, 0, c->stream, c->sc, qin, counts + b, c->d_hits, gcnt, c->d_spill, sstride);
+        }
+        {
+            LaunchTimer lt(c, RT_K_SHADE);
+            if (fix)
+                hipLaunchKernelGGL((k_shade<true>), grid_px, blk, 0, c->stream, c->sc, fa, b, qin, counts + b, c->d_hits, qout, counts + b + 1, prev, out);
+            else
+                hipLaunchKernelGGL((k_shade<false>), grid_px, blk, 0, c->stream, c->sc, fa, b, qin, counts + b, c->d_hits, qout, counts + b + 1, prev, out);
+        }
+    }
+    if (wf < p->ray_bounces) {
+        LaunchTimer lt(c, RT_K_TAIL);
+        DQueue q = c->q[wf & 1];
+        dim3 grid_tail(RT_TAIL_BLOCKS);
+#define TAIL(C_, F_) hipLaunchKernelGGL((k_tail<C_, F_>), grid_tail, blk, 0, c->stream, c->sc, fa, wf, q, counts + wf, prev, out, gcnt, c->d_spill, sstride)
+        if (count) { if (fix) TAIL(true, true); else TAIL(true, false); }
+        else { if (fix) TAIL(false, true); else TAIL(false, false); }
+#undef TAIL
+    }
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, float* d_accum) {
+    int rc = check_render_args(c, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!d_accum) return fail(c, RT_EINVAL, "d_accum is NULL");
+    uint32_t stride = p->frame_stride ? p->frame_stride : 1u;
+    if ((p->flags & RT_FLAG_SUM) && p->frame_base == 0)
+        HIPCHK(c, hipMemsetAsync(d_accum, 0, (size_t)p->width * p->height * 4 * sizeof(float), c->stream));
+    for (uint32_t f = 0; f < p->frames; f++) {
+        uint32_t fc = p->frame_base + f * stride;
+        rc = rt_raytrace_frame(c, cam, p, fc, d_accum, d_accum);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+
+int rt_render(rt_context* c, const rt_camera* cam, const rt_params* p, float* out_rgba) {
+    int rc = check_render_args(c, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!out_rgba) return fail(c, RT_EINVAL, "out_rgba is NULL");
+    size_t pixels = (size_t)p->width * p->height;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (pixels > c->frame_pixels) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dfree(c->d_frame);
+        HIPCHK(c, hipMalloc(&c->d_frame, pixels * sizeof(float4)));
+        c->frame_pixels = pixels;
+    }
+    if (p->frame_base != 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_frame, out_rgba, pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    else
+        HIPCHK(c, hipMemsetAsync(c->d_frame, 0, pixels * sizeof(float4), c->stream));
+    rc = rt_render_device(c, cam, p, (float*)c->d_frame);
+    if (rc != RT_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_rgba, c->d_frame, pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_primary_hits(rt_context* c, const rt_camera* cam, int32_t width, int32_t height, int32_t* out_ids, float* out_t) {
+    if (!c) return RT_EINVAL;
+    if (!cam || !out_ids || !out_t) return fail(c, RT_EINVAL, "NULL argument");
+    if (!c->has_scene) return fail(c, RT_ENOSCENE, "no scene uploaded");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)16384 * 16384)
+        return fail(c, RT_EINVAL, "bad image size %dx%d", width, height);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_buffers(c, width, height);
+    if (rc != RT_OK) return rc;
+    size_t pixels = (size_t)width * height;
+    int* d_ids = nullptr;
+    float* d_t = nullptr;
+    HIPCHK(c, hipMalloc(&d_ids, pixels * sizeof(int)));
+    HIPCHK(c, hipMalloc(&d_t, pixels * sizeof(float)));
+    DCamera dc = make_dcamera(cam, width, height);
+    int tiles_x = (width + 15) / 16, tiles = tiles_x * ((height + 15) / 16);
+    hipLaunchKernelGGL(k_primary_hits, dim3(tiles), dim3(RT_BLOCK), 0, c->stream, c->sc, dc, tiles_x, d_ids, d_t,
+                       c->d_spill, c->cap_slots);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_ids, pixels * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_t, pixels * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(d_ids);
+    dfree(d_t);
+    if (e != hipSuccess) return fail(c, RT_EDEVICE, "rt_primary_hits: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_counters(rt_context* c, uint64_t out[RT_NUM_COUNTERS]) {
+    if (!c) return RT_EINVAL;
+    if (!out) return fail(c, RT_EINVAL, "out is NULL");
+    unsigned long long tmp[RT_NUM_COUNTERS];
+    HIPCHK(c, hipMemcpyAsync(tmp, c->d_counters, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < RT_NUM_COUNTERS; k++) out[k] = tmp[k];
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_context* c) {
+    if (!c) return RT_EINVAL;
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
+    return RT_OK;
+}
+
+int rt_set_profiling(rt_context* c, int enable) {
+    if (!c) return RT_EINVAL;
+    c->profiling = enable != 0;
+    return RT_OK;
+}
+
+int rt_kernel_times(rt_context* c, float out_ms[RT_NUM_KERNEL_CLASSES], uint32_t out_launches[RT_NUM_KERNEL_CLASSES]) {
+    if (!c) return RT_EINVAL;
+    if (!out_ms || !out_launches) return fail(c, RT_EINVAL, "NULL argument");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& ep : c->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            c->ms[ep.cls] += ms;
+            c->launches[ep.cls]++;
+        }
+        c->free_events.push_back(ep);
+    }
+    c->pending.clear();
+    for (int k = 0; k < RT_NUM_KERNEL_CLASSES; k++) {
+        out_ms[k] = (float)c->ms[k];
+        out_launches[k] = c->launches[k];
+        c->ms[k] = 0.0;
+        c->launches[k] = 0;
+    }
+    return RT_OK;
+}
+
+int rt_selftest_math(rt_context* c, const float* x, int32_t n, float* out) {
+    if (!c) return RT_EINVAL;
+    if (!x || !out || n <= 0) return fail(c, RT_EINVAL, "bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&dx, (size_t)n * sizeof(float)));
+    HIPCHK(c, hipMalloc(&dout, (size_t)n * 6 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, dx, n, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dfree(dx);
+    dfree(dout);
+    if (e != hipSuccess) return fail(c, RT_EDEVICE, "rt_selftest_math: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"
