@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (and FPS) of the render path on the 80K-triangle scene at
+1920x1080, 1 spp per frame, full diffuse bounces with Russian roulette, bug-compatible mode.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one frame (one dispatch of the reference: one sample per pixel over the whole image) per
+GPU.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the frames are partitioned by
+sample index -- rank g renders frameCount g, g+N, ... of the same scene and camera into a private
+fp32 SUM buffer -- and one RCCL reduce of the accumulators to rank 0 closes the timed region; that is
+weak scaling (fixed work per GPU).  Rays are counted on the device (calls of the closest-hit routine,
+raytrace.glsl:245) in a separate untimed pass over exactly the timed frames.
+
+Besides the contract's fields the JSON line carries
+  roofline      algorithmic bytes of the dominant kernel / its mean launch duration (HIP events on
+                the launch stream, separate profiled pass) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference's GLSL path) timed on this host's cores on a
+                bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+WORKLOADS = {
+    # name: (obj, camera position, width, height)
+    "dragon80k_1080p": ("dragon80k.obj", (0.0, 0.0, -5.5), 1920, 1080),
+    "teapot_1080p": ("teapot.obj", (0.0, 0.0, -2.0), 1920, 1080),
+    "dragon80k_4k": ("dragon80k.obj", (0.0, 0.0, -5.5), 3840, 2160),
+}
+
+
+def algorithmic_bytes(c) -> float:
+    """Bytes the reference's own access pattern moves for the counted work: 32 B per box test (two
+    vec3 bounds padded to 16 B), 16 B per node pop (the child/leaf column), 48 B per triangle test
+    (three padded vertices), 32 B per hit (normal + colour) and 32 B per path (accumulator read +
+    write).  c = [box, tri, rays, hits, pops, paths]."""
+    box, tri, rays, hits, pops, paths = [float(x) for x in c]
+    return 32.0 * box + 16.0 * pops + 48.0 * tri + 32.0 * hits + 32.0 * paths
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "wavefront", "megakernel"])
+    ap.add_argument("--fix-invdir", action="store_true", help="non-default: refresh invDir after bounces")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            return 2
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    pkg = entry.load_package()
+    obj, cam_pos, W, H = WORKLOADS[args.workload]
+    scene = pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1)
+    cam = pkg.make_camera(pos=cam_pos)
+    ctx = pkg.RenderContext(local_rank)
+    ctx.upload_scene(scene)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    # N = 1 accumulates with the reference's running mean; N > 1 needs plain sums for the reduce
+    base_flags = pkg.RT_FLAG_SUM if world > 1 else 0
+    if args.fix_invdir:
+        base_flags |= pkg.RT_FLAG_FIX_INVDIR
+    if args.pipeline == "megakernel":
+        base_flags |= pkg.RT_FLAG_MEGAKERNEL
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+
+    def frame_index(step: int) -> int:
+        return step * world + rank
+
+    def render_step(step: int, flags: int, bounces: int = 100):
+        p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=frame_index(step), frames=1, flags=flags)
+        # frame_base may be 0 on rank 0: SUM mode would clear the buffer, so always continue from it
+        ctx.raytrace_frame(cam, p, frame_index(step), accum.data_ptr(), accum.data_ptr())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- warm-up (untimed) ------------------------------------------------------------------------
+    for s in range(args.warmup):
+        render_step(s, base_flags)
+    if dist is not None:
+        warm = accum.clone()
+        dist.reduce(warm, dst=0)
+        del warm
+    accum.zero_()
+
+    # ---- timed region: exactly K steps + the closing reduce -----------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        render_step(s, base_flags)
+    if dist is not None:
+        dist.reduce(accum, dst=0)
+    if rank == 0 and world > 1:
+        accum.mul_(1.0 / float(args.steps * world))  # sum -> mean image
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    image_mean = accum[..., :3].mean(dim=(0, 1)).tolist() if rank == 0 else None
+
+    # ---- untimed: count the rays of exactly those frames ---------------------------------------------
+    scratch = torch.zeros_like(accum)
+
+    def count_pass(flags, bounces=100):
+        ctx.reset_counters()
+        for s in range(args.steps):
+            p = pkg.make_params(W, H, ray_bounces=bounces, frames=1, flags=flags | pkg.RT_FLAG_COUNTERS)
+            ctx.raytrace_frame(cam, p, frame_index(s), scratch.data_ptr(), scratch.data_ptr())
+        return ctx.counters().astype(np.float64)
+
+    counters = count_pass(base_flags)
+    rays_local = counters[2]
+    if dist is not None:
+        tot = torch.tensor(counters, dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        counters_all = tot.cpu().numpy()
+    else:
+        counters_all = counters
+    total_rays = float(counters_all[2])
+    frames_total = args.steps * world
+
+    # ---- untimed: per-kernel durations with HIP events on the launch stream ------------------------
+    ctx.set_profiling(True)
+    for s in range(args.steps):
+        render_step(s, base_flags)
+    ms, launches = ctx.kernel_times()
+    ctx.set_profiling(False)
+    names = pkg.KERNEL_CLASS_NAMES
+    dominant = int(np.argmax(ms))
+    # algorithmic work of the dominant kernel class alone: for the wavefront extend kernel that is the
+    # traversal work of the first RT_WF_BOUNCES(=2) bounces, which a 2-bounce counting pass isolates
+    if names[dominant] == "extend":
+        dom_counters = count_pass(base_flags & ~pkg.RT_FLAG_MEGAKERNEL, bounces=2)
+        dom_counters[5] = 0.0  # the accumulator traffic belongs to the shade kernel
+        dom_counters[3] = 0.0  # so do the normal/colour fetches
+    else:
+        dom_counters = counters.copy()
+    dom_bytes_per_launch = algorithmic_bytes(dom_counters) / max(1, int(launches[dominant]))
+    dom_ms = float(ms[dominant]) / max(1, int(launches[dominant]))
+    achieved_gbs = dom_bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get(names[dominant], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        value = total_rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s, 80K-tri dragon stand-in 1080p 1spp" if args.workload == "dragon80k_1080p"
+            else f"Mrays/s, {args.workload}",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "fps": round(frames_total / elapsed, 2),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: fixtures/{obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
+                            f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
+                            f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}",
+                "pipeline": args.pipeline if args.pipeline != "auto" else "wavefront",
+                "frames_total": frames_total,
+                "parallelism": f"sample-partition x{world}" if world > 1 else "single GPU",
+            },
+            "rays_per_frame": round(total_rays / frames_total, 1),
+            "work_per_ray": {
+                "box_tests": round(counters_all[0] / total_rays, 3),
+                "tri_tests": round(counters_all[1] / total_rays, 3),
+                "node_pops": round(counters_all[4] / total_rays, 3),
+                "hit_fraction": round(counters_all[3] / total_rays, 4),
+                "rays_per_path": round(total_rays / counters_all[5], 4),
+                "algorithmic_bytes": round(algorithmic_bytes(counters_all) / total_rays, 1),
+            },
+            "kernels_ms_per_frame": {names[k]: round(float(ms[k]) / args.steps, 4) for k in range(len(names)) if launches[k]},
+            "image_mean_rgb": [round(x, 5) for x in image_mean],
+            "roofline": {
+                "bound": "hbm",
+                "kernel": names[dominant],
+                "achieved": round(achieved_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "launch_ms": round(dom_ms, 4),
+                "algorithmic_bytes_per_launch": round(dom_bytes_per_launch, 0),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, W, H, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    _ = rays_local
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return 0
+
+
+def cpu_baseline(pkg, scene, cam, W, H, budget_s):
+    """The oracle on this host's cores, on whole frames of the same workload until about budget_s
+    seconds of wall time are spent (at least one frame)."""
+    oracle = entry.load_oracle()
+    threads = min(oracle.max_threads(), 16)
+    nrm = oracle.normals(scene)
+    img = np.zeros((H, W, 4), dtype=np.float32)
+    p = pkg.make_params(W, H, frames=1)
+    rays = 0.0
+    frames = 0
+    t0 = time.perf_counter()
+    while True:
+        c = oracle.frame_rows(scene, nrm, cam, p, frames, img, 0, H, threads)
+        rays += float(c[2])
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or frames >= 64:
+            break
+    return {
+        "value": round(rays / dt / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{frames} full {W}x{H} frames (frameCount 0..{frames - 1}) of the same scene and camera, "
+                  f"{dt:.1f} s wall, OpenMP over image rows",
+        "fps": round(frames / dt, 3),
+    }
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Minimal render loop for profilers (rocprofv3 wraps `python3 prof_render.py ...` directly):
+no torch, no CPU baseline -- scene upload, a few warm-up frames, N frames through the C ABI."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+SCENES = {"dragon80k": ("dragon80k.obj", (0.0, 0.0, -5.5)), "teapot": ("teapot.obj", (0.0, 0.0, -2.0))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="dragon80k", choices=sorted(SCENES))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--fix-invdir", action="store_true")
+    ap.add_argument("--primary-only", action="store_true", help="time rt_primary_hits instead of full frames")
+    a = ap.parse_args()
+    pkg = entry.load_package()
+    obj, pos = SCENES[a.scene]
+    scene = pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1)
+    cam = pkg.make_camera(pos=pos)
+    ctx = pkg.RenderContext(0)
+    ctx.upload_scene(scene)
+    flags = (pkg.RT_FLAG_MEGAKERNEL if a.pipeline == "megakernel" else 0) | (pkg.RT_FLAG_FIX_INVDIR if a.fix_invdir else 0)
+    if a.primary_only:
+        t0 = time.perf_counter()
+        for _ in range(a.frames):
+            ctx.primary_hits(cam, a.width, a.height)
+        print(f"primary_hits: {(time.perf_counter() - t0) / a.frames * 1e3:.3f} ms per call (incl. download)")
+        return
+    import numpy as np
+    img = np.zeros((a.height, a.width, 4), dtype=np.float32)
+    ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags), img)
+    t0 = time.perf_counter()
+    ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.frames, flags=flags), img)
+    dt = time.perf_counter() - t0
+    print(f"{a.pipeline} {a.scene} {a.width}x{a.height}: {dt / a.frames * 1e3:.3f} ms per frame over {a.frames} frames (incl. one download)")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

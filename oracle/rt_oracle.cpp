@@ -406,6 +406,50 @@ void oracle_primary_hits(const rt_scene* s, const rt_camera* cam, int width, int
     }
 }
 
+// Per-pixel work statistics of one frame (analysis aid): number of rays of the pixel's paths, node pops of
+// its most expensive ray, and total node pops.
+void oracle_path_stats(const rt_scene* s, const float* normals, const rt_camera* cam, const rt_params* p,
+                       uint32_t frame_count, uint32_t* out_rays, uint32_t* out_max_pops, uint32_t* out_pops,
+                       int num_threads) {
+    Scene sc = make_scene(s, normals);
+    float pw = pixel_width(cam, p->width);
+    bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
+#ifdef _OPENMP
+    if (num_threads <= 0) num_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+#endif
+    for (int gy = 0; gy < p->height; gy++) {
+        for (int gx = 0; gx < p->width; gx++) {
+            uint32_t pixelIndex = (uint32_t)((float)gy * (float)p->width + (float)gx);
+            uint32_t seed = pixelIndex + frame_count * 745621u;
+            Ray ray = primary_ray(cam, pw, p->width, p->height, gx, gy);
+            rt_vec3 thr = rt_v3(1, 1, 1);
+            uint32_t rays = 0, maxp = 0, pops = 0;
+            for (uint32_t i = 0; i < p->ray_bounces; i++) {
+                PixelCounters pc;
+                HitInfo info = closest_hit(sc, ray, pc);
+                rays++;
+                pops += (uint32_t)pc.pops;
+                if (pc.pops > maxp) maxp = (uint32_t)pc.pops;
+                if (!(info.dist < RT_INF)) break;
+                ray.origin = rt_add(ray.origin, rt_scale(ray.dir, info.dist));
+                rt_vec3 normal = load3(sc.normals, info.triangleIndex);
+                if (rt_dot(normal, ray.dir) > 0.0f) normal = rt_neg(normal);
+                ray.dir = rand_direction_in_hemisphere(normal, &seed);
+                if (fix) ray.invDir = rt_v3(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+                if (i > 2) {
+                    if (rt_rand(&seed) > 0.8f) break;
+                }
+            }
+            (void)thr;
+            size_t at = (size_t)gy * p->width + gx;
+            out_rays[at] = rays;
+            out_max_pops[at] = maxp;
+            out_pops[at] = pops;
+        }
+    }
+}
+
 // ---- unit hooks for known-answer tests -------------------------------------------------------
 void oracle_rand(uint32_t seed, int n, uint32_t* raw, float* as_float) {
     for (int i = 0; i < n; i++) {

@@ -163,15 +163,11 @@ def test_sample_partition_sum_matches_running_mean(pkg, gpu_ctx, scenes):
     mean = gpu_ctx.render(cam, pkg.make_params(320, 180, frames=n))
     total = np.zeros_like(mean)
     for g in range(G):
+        # a non-zero frame_base continues from the passed buffer: zeros give this rank's own sum
+        part = np.zeros_like(mean)
         total += gpu_ctx.render(cam, pkg.make_params(320, 180, frames=n // G, frame_base=g, frame_stride=G,
-                                                     flags=pkg.RT_FLAG_SUM)) if g == 0 else _sum_part(pkg, gpu_ctx, cam, g, G, n)
+                                                     flags=pkg.RT_FLAG_SUM), part)
     assert rrmse(total / n, mean) < 1e-6
-
-
-def _sum_part(pkg, ctx, cam, g, G, n):
-    # frame_base != 0 in SUM mode continues from the passed buffer: pass zeros to get this rank's own sum
-    zeros = np.zeros((180, 320, 4), dtype=np.float32)
-    return ctx.render(cam, pkg.make_params(320, 180, frames=n // G, frame_base=g, frame_stride=G, flags=pkg.RT_FLAG_SUM), zeros)
 
 
 def test_malformed_scenes_are_rejected(pkg, gpu_ctx, scenes):
