@@ -55,7 +55,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "wavefront", "megakernel"])
+    ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true", help="non-default: refresh invDir after bounces")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -97,15 +97,16 @@ def main() -> int:
         base_flags |= pkg.RT_FLAG_FIX_INVDIR
     if args.pipeline == "megakernel":
         base_flags |= pkg.RT_FLAG_MEGAKERNEL
+    if args.pipeline == "wavefront":
+        base_flags |= pkg.RT_FLAG_WAVEFRONT
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
 
-    def frame_index(step: int) -> int:
-        return step * world + rank
-
-    def render_step(step: int, flags: int, bounces: int = 100):
-        p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=frame_index(step), frames=1, flags=flags)
-        # frame_base may be 0 on rank 0: SUM mode would clear the buffer, so always continue from it
-        ctx.raytrace_frame(cam, p, frame_index(step), accum.data_ptr(), accum.data_ptr())
+    def render_steps(first_step: int, nsteps: int, flags: int, target, bounces: int = 100):
+        """nsteps steps of this rank (frameCount (first_step+k)*world + rank) in ONE call of the boundary:
+        the library is free to render the frames of a call concurrently."""
+        p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=first_step * world + rank, frames=nsteps,
+                            frame_stride=world, flags=flags)
+        ctx.render_device(cam, p, target.data_ptr())
 
     def barrier():
         if dist is not None:
@@ -113,8 +114,8 @@ def main() -> int:
         torch.cuda.synchronize(dev)
 
     # ---- warm-up (untimed) ------------------------------------------------------------------------
-    for s in range(args.warmup):
-        render_step(s, base_flags)
+    if args.warmup:
+        render_steps(0, args.warmup, base_flags, accum)
     if dist is not None:
         warm = accum.clone()
         dist.reduce(warm, dst=0)
@@ -124,8 +125,7 @@ def main() -> int:
     # ---- timed region: exactly K steps + the closing reduce -----------------------------------------
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        render_step(s, base_flags)
+    render_steps(0, args.steps, base_flags, accum)
     if dist is not None:
         dist.reduce(accum, dst=0)
     if rank == 0 and world > 1:
@@ -143,9 +143,7 @@ def main() -> int:
 
     def count_pass(flags, bounces=100):
         ctx.reset_counters()
-        for s in range(args.steps):
-            p = pkg.make_params(W, H, ray_bounces=bounces, frames=1, flags=flags | pkg.RT_FLAG_COUNTERS)
-            ctx.raytrace_frame(cam, p, frame_index(s), scratch.data_ptr(), scratch.data_ptr())
+        render_steps(0, args.steps, flags | pkg.RT_FLAG_COUNTERS, scratch, bounces)
         return ctx.counters().astype(np.float64)
 
     counters = count_pass(base_flags)
@@ -161,8 +159,7 @@ def main() -> int:
 
     # ---- untimed: per-kernel durations with HIP events on the launch stream ------------------------
     ctx.set_profiling(True)
-    for s in range(args.steps):
-        render_step(s, base_flags)
+    render_steps(0, args.steps, base_flags, scratch)
     ms, launches = ctx.kernel_times()
     ctx.set_profiling(False)
     names = pkg.KERNEL_CLASS_NAMES
@@ -170,7 +167,7 @@ def main() -> int:
     # algorithmic work of the dominant kernel class alone: for the wavefront extend kernel that is the
     # traversal work of the first RT_WF_BOUNCES(=2) bounces, which a 2-bounce counting pass isolates
     if names[dominant] == "extend":
-        dom_counters = count_pass(base_flags & ~pkg.RT_FLAG_MEGAKERNEL, bounces=2)
+        dom_counters = count_pass(base_flags, bounces=2)
         dom_counters[5] = 0.0  # the accumulator traffic belongs to the shade kernel
         dom_counters[3] = 0.0  # so do the normal/colour fetches
     else:
@@ -209,7 +206,7 @@ def main() -> int:
                 "workload": f"{args.workload}: fixtures/{obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
                             f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
                             f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}",
-                "pipeline": args.pipeline if args.pipeline != "auto" else "wavefront",
+                "pipeline": args.pipeline,
                 "frames_total": frames_total,
                 "parallelism": f"sample-partition x{world}" if world > 1 else "single GPU",
             },

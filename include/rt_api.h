@@ -46,9 +46,13 @@ extern "C" {
                                      raytrace.glsl:247-254,288); OFF = bug-compatible default */
 #define RT_FLAG_SUM 0x2u          /* framebuffer receives the plain SUM of the frames' colours instead of
                                      the running mean (for sample-partitioned multi-GPU rendering) */
-#define RT_FLAG_MEGAKERNEL 0x4u   /* one thread follows one pixel's whole path (the reference's dispatch
-                                     shape) instead of the wavefront generate/extend/shade pipeline */
+#define RT_FLAG_MEGAKERNEL 0x4u   /* pipeline: one thread follows one pixel's whole sample loop, one launch per
+                                     frame (the reference's dispatch shape) */
 #define RT_FLAG_COUNTERS 0x8u     /* also accumulate the work counters read by rt_counters() */
+#define RT_FLAG_WAVEFRONT 0x10u   /* pipeline: separate generate / extend / shade+compact kernels over ray
+                                     queues in HBM, one frame at a time.  Without a pipeline flag the default
+                                     is the persistent path kernel, which renders batches of frames
+                                     concurrently.  All pipelines produce identical pixels. */
 
 /* Scene in the layout the reference uploads (raytrace.cpp:38-54, scene-loader.h:7-15):
  *   nodes    num_nodes x 12 floats, AlignedMat3 {min.xyz,_}{max.xyz,_}{isLeaf,a,b,_};
@@ -159,7 +163,8 @@ int rt_reset_counters(rt_context* ctx);
 #define RT_K_TAIL 3
 #define RT_K_ACCUMULATE 4
 #define RT_K_MEGA 5
-#define RT_NUM_KERNEL_CLASSES 6
+#define RT_K_PATHS 6
+#define RT_NUM_KERNEL_CLASSES 7
 /* enable != 0: bracket every kernel launch with HIP events on the context's stream (adds
  * event overhead; keep it off in throughput runs).  rt_kernel_times synchronises and
  * returns the summed milliseconds and launch counts per class since profiling was enabled

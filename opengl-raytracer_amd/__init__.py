@@ -24,9 +24,10 @@ RT_FLAG_FIX_INVDIR = 0x1
 RT_FLAG_SUM = 0x2
 RT_FLAG_MEGAKERNEL = 0x4
 RT_FLAG_COUNTERS = 0x8
+RT_FLAG_WAVEFRONT = 0x10
 RT_NUM_COUNTERS = 6
-RT_NUM_KERNEL_CLASSES = 6
-KERNEL_CLASS_NAMES = ["generate", "extend", "shade", "tail", "accumulate", "mega"]
+RT_NUM_KERNEL_CLASSES = 7
+KERNEL_CLASS_NAMES = ["generate", "extend", "shade", "tail", "accumulate", "mega", "paths"]
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -159,7 +160,8 @@ def load_hip() -> C.CDLL:
     """Loads librt_hip.so; raises if it has not been built (no fallback exists)."""
     global _hip
     if _hip is None:
-        path = os.path.join(CSRC, "librt_hip.so")
+        # RT_HIP_LIB lets a developer load an instrumented build of the same library
+        path = os.environ.get("RT_HIP_LIB") or os.path.join(CSRC, "librt_hip.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (make -C {CSRC})")
         lib = C.CDLL(path)

@@ -27,6 +27,7 @@
 
 #include "rt_api.h"
 #include "rt_device.h"
+#include "rt_paths.h"
 
 #define RT_WF_BOUNCES 2       // bounces handled by wavefront kernels before the tail launch
 #define RT_TAIL_BLOCKS 1024   // grid of the tail kernel (grid-stride)
@@ -366,6 +367,14 @@ struct rt_context {
     float4* d_frame = nullptr;  // framebuffer for the host-pointer entry points
     size_t frame_pixels = 0;
 
+    // persistent path kernel
+    int num_cus = 0;
+    int cache_recs = 0;           // inner-node records that are laid out breadth-first at the front
+    float4* d_samples = nullptr;  // [PT_MAX_BATCH][pixels] staging
+    size_t samples_pixels = 0;
+    uint2* d_pspill = nullptr;
+    size_t pspill_entries = 0;
+
     unsigned long long* d_counters = nullptr;
 
     bool profiling = false;
@@ -420,6 +429,10 @@ static void free_buffers(rt_context* c) {
     dfree(c->d_spill);
     c->cap_slots = 0;
     c->spill_entries = 0;
+    dfree(c->d_samples);
+    c->samples_pixels = 0;
+    dfree(c->d_pspill);
+    c->pspill_entries = 0;
 }
 
 // Brackets one launch with events when profiling is on.
@@ -499,6 +512,76 @@ static DCamera make_dcamera(const rt_camera* cam, int width, int height) {
     return d;
 }
 
+// Buffers of the persistent path kernel: sample staging for one batch and the stack spill area.
+static int ensure_paths_buffers(rt_context* c, size_t pixels) {
+    size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
+    if (pixels <= c->samples_pixels && want_spill <= c->pspill_entries) return RT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (pixels > c->samples_pixels) {
+        dfree(c->d_samples);
+        c->samples_pixels = 0;
+        HIPCHK(c, hipMalloc(&c->d_samples, (size_t)PT_MAX_BATCH * pixels * sizeof(float4)));
+        c->samples_pixels = pixels;
+    }
+    if (want_spill > c->pspill_entries) {
+        dfree(c->d_pspill);
+        c->pspill_entries = 0;
+        HIPCHK(c, hipMalloc(&c->d_pspill, want_spill * (size_t)c->num_cus * PT_BLOCK * sizeof(uint2)));
+        c->pspill_entries = want_spill;
+    }
+    return RT_OK;
+}
+
+// Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
+// them, in order, into out (reading prev).
+static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
+                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out) {
+    const bool sum = (p->flags & RT_FLAG_SUM) != 0;
+    const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    size_t pixels = (size_t)p->width * p->height;
+    int rc = ensure_paths_buffers(c, pixels);
+    if (rc != RT_OK) return rc;
+    PathsArgs a;
+    a.frame_base = frame_base;
+    a.frame_stride = stride;
+    a.num_frames = nframes;
+    a.bounces = p->ray_bounces;
+    a.tiles_x = (p->width + 7) / 8;
+    a.tiles_per_frame = a.tiles_x * ((p->height + 7) / 8);
+    a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
+    a.pixels = (uint32_t)pixels;
+    a.cache_recs = c->cache_recs;
+    a.min_trav = PT_MIN_TRAV;
+    a.min_service = PT_MIN_SERVICE;
+    // developer knobs for tuning runs
+    if (const char* e = getenv("RT_TUNE_MIN_TRAV")) a.min_trav = atoi(e);
+    if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) a.min_service = atoi(e);
+    if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }
+    a.samples = c->d_samples;
+    a.spill = c->d_pspill;
+    a.spill_stride = (size_t)c->num_cus * PT_BLOCK;
+    a.counters = count ? c->d_counters : nullptr;
+    dim3 grid(c->num_cus), blk(PT_BLOCK);
+    {
+        LaunchTimer lt(c, RT_K_PATHS);
+#define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, c->stream, c->sc, dc, a)
+        if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
+        else { if (fix) PATHS(false, true); else PATHS(false, false); }
+#undef PATHS
+    }
+    HIPCHK(c, hipGetLastError());
+    {
+        LaunchTimer lt(c, RT_K_ACCUMULATE);
+        uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, c->stream,
+                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, frame_base, stride, sum ? 1u : 0u,
+                           read_prev, prev, out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" {
 
 const char* rt_version(void) { return "rt_hip gfx950 " __DATE__; }
@@ -517,14 +600,17 @@ int rt_create(int device_id, rt_context** out_ctx) {
     rt_context* c = new rt_context();
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->own_stream)) != hipSuccess ||
-        (e = hipMalloc(&c->d_counters, RT_NUM_COUNTERS * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&c->d_counts, 64 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMemset(c->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemset(c->d_counters, 0, 16 * sizeof(unsigned long long))) != hipSuccess) {
         int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
         delete c;
         return rc;
     }
     c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+                     ? prop.multiProcessorCount : 256;
     *out_ctx = c;
     return RT_OK;
 }
@@ -573,39 +659,95 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     const int N = s->num_nodes, T = s->num_tris;
     if (N < 1 || T < 1) return fail(c, RT_EINVAL, "scene needs at least one node and one triangle");
 
-    struct Item {
-        int node, depth, parent_rec, slot;
+    // Pass 1: validate the tree depth-first (first child first) and remember the visiting order.
+    struct Visit {
+        int node, depth, parent, slot;  // parent = position of the parent in `order` (-1: root)
+        bool leaf;
+        int a, b;
     };
-    std::vector<float> recs;        // 16 floats per inner node
-    std::vector<float> tris;        // 12 floats per leaf-ordered triangle
+    std::vector<Visit> order;
+    order.reserve((size_t)N);
     std::vector<char> seen((size_t)N, 0);
-    std::vector<Item> todo;
-    recs.reserve((size_t)N * 8);
+    {
+        struct Item {
+            int node, depth, parent, slot;
+        };
+        std::vector<Item> todo;
+        todo.push_back({0, 0, -1, 0});
+        while (!todo.empty()) {
+            Item it = todo.back();
+            todo.pop_back();
+            if (it.node < 0 || it.node >= N) return fail(c, RT_EINVAL, "node index %d out of range", it.node);
+            if (seen[it.node]) return fail(c, RT_EINVAL, "node %d is referenced twice (not a tree)", it.node);
+            seen[it.node] = 1;
+            if (it.depth > RT_MAX_DEPTH) return fail(c, RT_ELIMIT, "tree deeper than %d levels", RT_MAX_DEPTH);
+            const float* nd = s->nodes + (size_t)12 * it.node;
+            Visit v;
+            v.node = it.node;
+            v.depth = it.depth;
+            v.parent = it.parent;
+            v.slot = it.slot;
+            v.leaf = std::fabs(nd[8] - 1.0f) <= RT_EPS;  // raytrace.glsl:155
+            v.a = (int)nd[9];                             // raytrace.glsl:157-158,167-168
+            v.b = (int)nd[10];
+            int pos = (int)order.size();
+            if (v.leaf) {
+                if (v.b >= v.a && (v.a < 0 || v.b >= T))
+                    return fail(c, RT_EINVAL, "leaf %d: triangle range [%d,%d] out of range", it.node, v.a, v.b);
+            } else {
+                if (v.a < 0 || v.a >= N || v.b < 0 || v.b >= N)
+                    return fail(c, RT_EINVAL, "node %d: child index out of range", it.node);
+                todo.push_back({v.b, it.depth + 1, pos, 1});
+                todo.push_back({v.a, it.depth + 1, pos, 0});
+            }
+            order.push_back(v);
+        }
+    }
+    // Pass 2: record indices.  The first PT_CACHE inner nodes in BREADTH-first order get indices
+    // 0..K-1 (the persistent kernel stages exactly that prefix in LDS); all others follow depth-first,
+    // which keeps subtrees contiguous in memory.
+    const int V = (int)order.size();
+    std::vector<int> rec_of(V, -1), kids(2 * (size_t)V, -1);
+    int num_inner = 0, max_depth = 0;
+    for (int i = 0; i < V; i++) {
+        if (order[i].parent >= 0) kids[2 * (size_t)order[i].parent + order[i].slot] = i;
+        if (!order[i].leaf) num_inner++;
+        if (order[i].depth > max_depth) max_depth = order[i].depth;
+    }
+    int next_rec = 0;
+    {
+        std::vector<int> level{0}, nxt;
+        while (!level.empty() && next_rec < PT_CACHE) {
+            nxt.clear();
+            for (int i : level) {
+                if (order[i].leaf) continue;
+                if (next_rec < PT_CACHE) rec_of[i] = next_rec++;
+                nxt.push_back(kids[2 * (size_t)i]);
+                nxt.push_back(kids[2 * (size_t)i + 1]);
+            }
+            level.swap(nxt);
+        }
+    }
+    const int cache_recs = next_rec;
+    for (int i = 0; i < V; i++)
+        if (!order[i].leaf && rec_of[i] < 0) rec_of[i] = next_rec++;
+    // Pass 3: fill the records.
+    std::vector<float> recs((size_t)num_inner * 16, 0.0f);  // 16 floats per inner node
+    std::vector<float> tris;                                 // 12 floats per leaf-ordered triangle
     tris.reserve((size_t)T * 12);
-    int root_ref = 0, max_depth = 0;
+    int root_ref = 0;
     auto as_f = [](int v) { return rt_u2f((uint32_t)v); };
-    todo.push_back({0, 0, -1, 0});
-    while (!todo.empty()) {
-        Item it = todo.back();
-        todo.pop_back();
-        if (it.node < 0 || it.node >= N) return fail(c, RT_EINVAL, "node index %d out of range", it.node);
-        if (seen[it.node]) return fail(c, RT_EINVAL, "node %d is referenced twice (not a tree)", it.node);
-        seen[it.node] = 1;
-        if (it.depth > RT_MAX_DEPTH) return fail(c, RT_ELIMIT, "tree deeper than %d levels", RT_MAX_DEPTH);
-        if (it.depth > max_depth) max_depth = it.depth;
-        const float* nd = s->nodes + (size_t)12 * it.node;
-        bool leaf = std::fabs(nd[8] - 1.0f) <= RT_EPS;  // raytrace.glsl:155
-        int a = (int)nd[9], b = (int)nd[10];             // raytrace.glsl:157-158,167-168
+    for (int i = 0; i < V; i++) {
+        const Visit& v = order[i];
         int ref;
-        if (leaf) {
-            if (b < a) {
+        if (v.leaf) {
+            if (v.b < v.a) {
                 ref = RT_REF_EMPTY;
             } else {
-                if (a < 0 || b >= T) return fail(c, RT_EINVAL, "leaf %d: triangle range [%d,%d] out of range", it.node, a, b);
                 ref = ~(int)(tris.size() / 12);
-                for (int k = a; k <= b; k++) {
+                for (int k = v.a; k <= v.b; k++) {
                     const float *p0 = s->triv0 + 4 * (size_t)k, *p1 = s->triv1 + 4 * (size_t)k, *p2 = s->triv2 + 4 * (size_t)k;
-                    float rec[12] = {p0[0], p0[1], p0[2], as_f(k == b ? 1 : 0),
+                    float rec[12] = {p0[0], p0[1], p0[2], as_f(k == v.b ? 1 : 0),
                                      p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], as_f(k),
                                      p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f};
                     tris.insert(tris.end(), rec, rec + 12);
@@ -613,26 +755,18 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
                 if (tris.size() / 12 > (size_t)0x7ffffff0) return fail(c, RT_ELIMIT, "too many triangle records");
             }
         } else {
-            if (a < 0 || a >= N || b < 0 || b >= N) return fail(c, RT_EINVAL, "node %d: child index out of range", it.node);
-            ref = (int)(recs.size() / 16);
-            recs.resize(recs.size() + 16, 0.0f);
-            // children are expanded depth-first, first child next (keeps subtrees contiguous)
-            todo.push_back({b, it.depth + 1, ref, 1});
-            todo.push_back({a, it.depth + 1, ref, 0});
+            ref = rec_of[i];
         }
-        if (it.parent_rec < 0) {
+        if (v.parent < 0) {
             root_ref = ref;
         } else {
-            float* pr = recs.data() + (size_t)16 * it.parent_rec;
-            const float* mn = nd;
-            const float* mx = nd + 4;
-            if (it.slot == 0) {
-                pr[0] = mn[0]; pr[1] = mn[1]; pr[2] = mn[2]; pr[3] = mx[0]; pr[4] = mx[1]; pr[5] = mx[2];
-                pr[12] = as_f(ref);
-            } else {
-                pr[6] = mn[0]; pr[7] = mn[1]; pr[8] = mn[2]; pr[9] = mx[0]; pr[10] = mx[1]; pr[11] = mx[2];
-                pr[13] = as_f(ref);
-            }
+            float* pr = recs.data() + (size_t)16 * rec_of[v.parent];
+            const float* mn = s->nodes + (size_t)12 * v.node;
+            const float* mx = mn + 4;
+            int o = v.slot == 0 ? 0 : 6;
+            pr[o + 0] = mn[0]; pr[o + 1] = mn[1]; pr[o + 2] = mn[2];
+            pr[o + 3] = mx[0]; pr[o + 4] = mx[1]; pr[o + 5] = mx[2];
+            pr[12 + v.slot] = as_f(ref);
         }
     }
 
@@ -676,6 +810,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     c->sc.num_tris = T;
     c->num_tris = T;
     c->max_depth = max_depth;
+    c->cache_recs = cache_recs;
     c->has_scene = true;
     // a deeper tree may need a larger spill area: force re-allocation on the next render
     if (c->max_depth > RT_LDS_STACK && (size_t)(c->max_depth - RT_LDS_STACK + 1) > c->spill_entries) free_buffers(c);
@@ -703,11 +838,14 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     const bool mega = (p->flags & RT_FLAG_MEGAKERNEL) != 0 || p->render_mode != RT_MODE_RENDER ||
                       p->rays_per_pixel != 1 || p->ray_bounces == 0;
+    const bool wavefront = !mega && (p->flags & RT_FLAG_WAVEFRONT) != 0;
     if (!d_prev_frame && (sum || frame_count != 0)) return fail(c, RT_EINVAL, "d_prev_frame is NULL for frame %u", frame_count);
     HIPCHK(c, hipSetDevice(c->device));
+    DCamera dc = make_dcamera(cam, p->width, p->height);
+    if (!mega && !wavefront)
+        return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame);
     if ((rc = ensure_buffers(c, p->width, p->height)) != RT_OK) return rc;
 
-    DCamera dc = make_dcamera(cam, p->width, p->height);
     FrameArgs fa;
     fa.frame = frame_count;
     fa.bounces = p->ray_bounces;
@@ -777,9 +915,21 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     uint32_t stride = p->frame_stride ? p->frame_stride : 1u;
     if ((p->flags & RT_FLAG_SUM) && p->frame_base == 0)
         HIPCHK(c, hipMemsetAsync(d_accum, 0, (size_t)p->width * p->height * 4 * sizeof(float), c->stream));
-    for (uint32_t f = 0; f < p->frames; f++) {
-        uint32_t fc = p->frame_base + f * stride;
-        rc = rt_raytrace_frame(c, cam, p, fc, d_accum, d_accum);
+    const bool per_frame = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) != 0 ||
+                           p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 || p->ray_bounces == 0;
+    if (per_frame) {
+        for (uint32_t f = 0; f < p->frames; f++) {
+            uint32_t fc = p->frame_base + f * stride;
+            rc = rt_raytrace_frame(c, cam, p, fc, d_accum, d_accum);
+            if (rc != RT_OK) return rc;
+        }
+        return RT_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    DCamera dc = make_dcamera(cam, p->width, p->height);
+    for (uint32_t f = 0; f < p->frames; f += PT_MAX_BATCH) {
+        uint32_t n = p->frames - f < PT_MAX_BATCH ? p->frames - f : PT_MAX_BATCH;
+        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum);
         if (rc != RT_OK) return rc;
     }
     return RT_OK;
@@ -843,12 +993,21 @@ int rt_counters(rt_context* c, uint64_t out[RT_NUM_COUNTERS]) {
     HIPCHK(c, hipMemcpyAsync(tmp, c->d_counters, sizeof tmp, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < RT_NUM_COUNTERS; k++) out[k] = tmp[k];
+#ifdef PT_DIAG
+    {
+        unsigned long long d[8];
+        (void)hipMemcpy(d, c->d_counters + 8, sizeof d, hipMemcpyDeviceToHost);
+        fprintf(stderr, "PT_DIAG inner iters %llu lanes/iter %.2f | leaf phases %llu lanes/phase %.2f | service iters %llu lanes/iter %.2f | tri iters %llu lanes/iter %.2f\n",
+                d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[2], d[2] ? (double)d[3] / d[2] : 0.0, d[4], d[4] ? (double)d[5] / d[4] : 0.0,
+                d[6], d[6] ? (double)d[7] / d[6] : 0.0);
+    }
+#endif
     return RT_OK;
 }
 
 int rt_reset_counters(rt_context* c) {
     if (!c) return RT_EINVAL;
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, RT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 

@@ -1,0 +1,364 @@
+// Persistent path kernel: the default pipeline of the render path on MI355X.
+//
+// One launch renders a BATCH of frames.  The grid is one 1024-thread workgroup per CU; every wave is an
+// independent worker that keeps its 64 lanes busy with paths drawn from a pool of (frame, 8x8 pixel tile)
+// items, so that lanes whose path has ended (60 % of primary rays leave the scene at once) do not idle while
+// their neighbours traverse.  Each wave alternates two phases, each of which runs one kind of code on as many
+// lanes as possible:
+//
+//   service   shade the lanes whose traversal has finished (bounce + Russian roulette, or sky and sample
+//             store), refill empty lanes with new primary rays (wave ballot + mbcnt prefix over the empty
+//             lanes, tiles handed out by a workgroup-local LDS counter -- no global atomics at all), and run
+//             the root-box test of every new ray;
+//   traverse  ordered BVH traversal, itself split in an inner-node loop and a leaf loop, until too few lanes
+//             are still traversing.
+//
+// Memory placement (LDS is 160 KiB per CU and one workgroup owns all of it):
+//   traversal stacks   12 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict:
+//                      96 KiB; deeper entries (rare) spill to HBM, coalesced across the wave
+//   top of the BVH     the first PT_CACHE inner-node records (breadth-first, ~10 levels of an 80K-triangle
+//                      tree) are staged in LDS once per workgroup: 62.5 KiB.  Quads of a record are XOR-
+//                      swizzled so that lanes reading different records spread over all 16-byte bank slots
+//   everything else    registers: ray, throughput, RNG state, pixel, bounce index, traversal cursor
+//
+// Samples go to a staging array [frame][pixel]; k_accumulate folds them into the framebuffer in frame order,
+// which keeps the running mean of raytrace.glsl:296 bit-exact although frames are rendered concurrently.
+#ifndef RT_PATHS_H
+#define RT_PATHS_H
+
+#include "rt_device.h"
+
+#define PT_BLOCK 1024
+#define PT_STACK 12
+#define PT_CACHE 1000          // inner-node records staged in LDS (64 B each)
+#define PT_MIN_TRAV 24         // leave the traversal phase when fewer lanes than this still traverse ...
+#define PT_MIN_SERVICE 8       // ... and keep servicing only while at least this many lanes need it
+#define PT_MAX_BATCH 8         // frames per launch
+
+enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
+
+struct PathsArgs {
+    uint32_t frame_base, frame_stride, num_frames;
+    uint32_t bounces;
+    int tiles_x, tiles_per_frame;   // 8x8 pixel tiles
+    uint32_t total_tiles;           // num_frames * tiles_per_frame
+    uint32_t pixels;                // width * height
+    int cache_recs;                 // records actually staged (<= PT_CACHE)
+    int min_trav, min_service;      // phase-switch thresholds (lanes)
+    float4* samples;                // [num_frames][pixels]
+    uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
+    size_t spill_stride;
+    unsigned long long* counters;
+};
+
+__device__ __forceinline__ void flush_counters6(const Counters& cn, unsigned long long paths, unsigned long long* g) {
+    unsigned long long v[6] = {cn.box, cn.tri, cn.rays, cn.hits, cn.pops, paths};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        unsigned long long x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&g[k], x);
+    }
+}
+
+// Spill accesses are volatile so that the compiler keeps them apart from the LDS accesses of the same
+// stack slot instead of merging both into one flat access through a generic pointer.
+__device__ __forceinline__ void spill_store(uint2* p, uint2 v) {
+    volatile uint32_t* q = (volatile uint32_t*)p;
+    q[0] = v.x;
+    q[1] = v.y;
+}
+__device__ __forceinline__ uint2 spill_load(const uint2* p) {
+    const volatile uint32_t* q = (const volatile uint32_t*)p;
+    uint2 v;
+    v.x = q[0];
+    v.y = q[1];
+    return v;
+}
+
+template <bool COUNT, bool FIX>
+__global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, PathsArgs a) {
+    __shared__ uint2 s_stack[PT_STACK][PT_BLOCK];
+    __shared__ float4 s_nodes[PT_CACHE * 4];
+    __shared__ uint32_t s_next;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < a.cache_recs * 4; i += PT_BLOCK) {
+        int r = i >> 2, q = i & 3;
+        s_nodes[(r << 2) + (q ^ ((r >> 2) & 3))] = sc.nodes[i];
+    }
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // byte offset of the staged records inside this workgroup's LDS allocation
+    const uint32_t nodes_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&s_nodes[0];
+    uint2* const spill = a.spill ? a.spill + ((size_t)blockIdx.x * PT_BLOCK + tid) : nullptr;
+    const size_t spill_stride = a.spill_stride;
+#define PT_PUT(i_, ref_, dist_)                                              \
+    do {                                                                     \
+        uint2 v_ = make_uint2((uint32_t)(ref_), rt_f2u(dist_));             \
+        if ((i_) < PT_STACK)                                                 \
+            s_stack[(i_)][tid] = v_;                                         \
+        else                                                                 \
+            spill_store(spill + (size_t)((i_)-PT_STACK) * spill_stride, v_); \
+    } while (0)
+#define PT_GET(e_, i_)                                                       \
+    do {                                                                     \
+        if ((i_) < PT_STACK)                                                 \
+            e_ = s_stack[(i_)][tid];                                         \
+        else                                                                 \
+            e_ = spill_load(spill + (size_t)((i_)-PT_STACK) * spill_stride); \
+    } while (0)
+
+    // wave-uniform cursor into the tile pool
+    uint32_t tile_g = 0;
+    int tile_off = 64;
+    bool exhausted = false;
+
+    // lane state
+    int state = ST_NEED;
+    PathState p;
+    p.o = p.d = p.inv = p.thr = rt_v3(0.0f, 0.0f, 0.0f);
+    p.seed = 0;
+    uint32_t out_idx = 0, bnc = 0;
+    int cur = 0, sp = 0, best_id = -1;
+    float best = RT_INF;
+    Counters cn = {0, 0, 0, 0, 0};
+    unsigned long long paths = 0;
+#ifdef PT_DIAG
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// iteration counters (even k): only the first active lane counts; lane sums (odd k): every active lane adds 1
+#define DIAG(k_, v_) dg[k_] += ((k_) & 1) ? 1ull : (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u ? 1ull : 0ull)
+#else
+#define DIAG(k_, v_)
+#endif
+
+    for (;;) {
+        // ------------------------------------------------------------------ service phase
+        for (;;) {
+            DIAG(4, 1);
+            if (state == ST_DONE || (state == ST_NEED && !exhausted)) { DIAG(5, 1); }
+            if (state == ST_DONE) {
+                rt_vec3 result = rt_v3(0.0f, 0.0f, 0.0f);
+                bool ended = true;
+                if (best < RT_INF) {
+                    if (COUNT) cn.hits++;
+                    bool alive = bounce<FIX>(sc, p, best, best_id, bnc);
+                    bnc++;
+                    if (alive && bnc < a.bounces) {
+                        ended = false;
+                        state = ST_NEW;
+                    }
+                } else {
+                    result = rt_mul(sample_sky(p.d), p.thr);
+                }
+                if (ended) {
+                    a.samples[out_idx] = make_float4(result.x, result.y, result.z, 2.0f);
+                    state = ST_NEED;
+                }
+            }
+            unsigned long long need = __ballot(state == ST_NEED);
+            if (need != 0ull && !exhausted) {
+                if (tile_off >= 64) {
+                    uint32_t k = 0;
+                    if ((tid & 63) == 0) k = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                    tile_g = blockIdx.x + k * gridDim.x;
+                    tile_off = 0;
+                    if (tile_g >= a.total_tiles) exhausted = true;
+                }
+                if (!exhausted) {
+                    int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    int avail = 64 - tile_off;
+                    if (state == ST_NEED && rank < avail) {
+                        int l = tile_off + rank;
+                        uint32_t f = tile_g / (uint32_t)a.tiles_per_frame;
+                        int t = (int)(tile_g - f * (uint32_t)a.tiles_per_frame);
+                        int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                        int gx = tx * 8 + (l & 7), gy = ty * 8 + (l >> 3);
+                        if (gx < cam.width && gy < cam.height) {
+                            primary_ray(cam, gx, gy, p.o, p.d, p.inv);
+                            p.seed = pixel_seed(cam, gx, gy, a.frame_base + f * a.frame_stride);
+                            p.thr = rt_v3(1.0f, 1.0f, 1.0f);
+                            out_idx = f * a.pixels + (uint32_t)gy * (uint32_t)cam.width + (uint32_t)gx;
+                            bnc = 0;
+                            state = ST_NEW;
+                            if (COUNT) paths++;
+                        }
+                    }
+                    int taken = __popcll(need);
+                    tile_off += taken < avail ? taken : avail;
+                }
+            }
+            if (state == ST_NEW) {
+                if (COUNT) {
+                    cn.rays++;
+                    cn.box++;
+                }
+                float d0 = box_dist(p.o, p.inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2]);
+                best = RT_INF;
+                best_id = -1;
+                if (d0 == RT_INF) {
+                    state = ST_DONE;
+                } else {
+                    if (COUNT) cn.box++;
+                    cur = sc.root_ref;
+                    if (COUNT && cur < 0) cn.pops++;
+                    sp = 0;
+                    state = ST_TRAV;
+                }
+            }
+            unsigned long long pending = __ballot(state == ST_DONE || (state == ST_NEED && !exhausted));
+            if (pending == 0ull) break;
+            if (__popcll(pending) < a.min_service && __ballot(state == ST_TRAV) != 0ull) break;
+        }
+
+        if (__ballot(state == ST_TRAV) == 0ull) {
+            // nothing traverses: either everything is finished or only stragglers wait for service
+            if (__ballot(state == ST_DONE || (state == ST_NEED && !exhausted)) == 0ull) break;
+            continue;
+        }
+
+        // ------------------------------------------------------------------ traversal phase
+        // Every iteration runs ONE kind of step -- an inner-node visit or a triangle test -- chosen by
+        // which of the two more lanes are waiting for; the other lanes keep their state and wait.
+#define PT_POP()                                             \
+    for (;;) {                                               \
+        if (sp == 0) {                                       \
+            state = ST_DONE;                                 \
+            break;                                           \
+        }                                                    \
+        sp--;                                                \
+        uint2 e_;                                            \
+        PT_GET(e_, sp);                                      \
+        if (!(rt_u2f(e_.y) >= best)) {                       \
+            cur = (int)e_.x;                                 \
+            if (COUNT && cur < 0) cn.pops++;                 \
+            break;                                           \
+        }                                                    \
+    }
+        for (;;) {
+            const bool want_inner = state == ST_TRAV && cur >= 0;
+            const bool want_leaf = state == ST_TRAV && cur < 0;
+            const unsigned long long mi = __ballot(want_inner), ml = __ballot(want_leaf);
+            const int ni = __popcll(mi), nl = __popcll(ml);
+            if (ni + nl == 0) break;
+            if (ni + nl < a.min_trav && __ballot(state == ST_DONE || (state == ST_NEED && !exhausted)) != 0ull) break;
+            if (ni >= nl) {
+                if (want_inner) {
+                    DIAG(0, 1);
+                    DIAG(1, 1);
+                    // Staged records come from LDS, the others from HBM, straight into the same four
+                    // registers: one asm statement narrows EXEC to each group in turn.  (Written in C++
+                    // the compiler fuses both sources into per-dword FLAT loads through a generic pointer,
+                    // 13 memory instructions per visit instead of 4.)
+                    f4 q0, q1, q2, q3;
+                    {
+                        const unsigned long long staged = __ballot(cur < a.cache_recs);
+                        const uint32_t cc = (uint32_t)cur;
+                        const uint32_t base = nodes_lds + (cc << 6), x = (cc >> 2) & 3u;
+                        const float4* rec = sc.nodes + (size_t)cc * 4;
+                        unsigned long long keep;
+                        asm volatile(
+                            "s_mov_b64 %4, exec\n\t"
+                            "s_and_b64 exec, %4, %5\n\t"
+                            "ds_read_b128 %0, %6\n\t"
+                            "ds_read_b128 %1, %7\n\t"
+                            "ds_read_b128 %2, %8\n\t"
+                            "ds_read_b128 %3, %9\n\t"
+                            "s_andn2_b64 exec, %4, %5\n\t"
+                            "global_load_dwordx4 %0, %10, off\n\t"
+                            "global_load_dwordx4 %1, %10, off offset:16\n\t"
+                            "global_load_dwordx4 %2, %10, off offset:32\n\t"
+                            "global_load_dwordx4 %3, %10, off offset:48\n\t"
+                            "s_mov_b64 exec, %4\n\t"
+                            "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                            : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&s"(keep)
+                            : "s"(staged), "v"(base + (x << 4)), "v"(base + ((1u ^ x) << 4)), "v"(base + ((2u ^ x) << 4)),
+                              "v"(base + ((3u ^ x) << 4)), "v"(rec)
+                            : "memory");
+                    }
+                    if (COUNT) {
+                        cn.pops++;
+                        cn.box += 2;
+                    }
+                    float d1 = box_dist(p.o, p.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                    float d2 = box_dist(p.o, p.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                    int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
+                    bool first_is_1 = d1 < d2;
+                    int rn = first_is_1 ? r1 : r2, rf = first_is_1 ? r2 : r1;
+                    float dn = first_is_1 ? d1 : d2, df = first_is_1 ? d2 : d1;
+                    if (df < best) {
+                        PT_PUT(sp, rf, df);
+                        sp++;
+                    }
+                    if (dn < best) {
+                        cur = rn;
+                        if (COUNT && cur < 0) cn.pops++;
+                    } else {
+                        PT_POP();
+                    }
+                }
+            } else {
+                if (want_leaf) {
+                    DIAG(6, 1);
+                    DIAG(7, 1);
+                    bool last = true;
+                    if (cur != RT_REF_EMPTY) {
+                        const int k = ~cur;
+                        const float4* tr = sc.tris + (size_t)k * 3;
+                        float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
+                        if (COUNT) cn.tri++;
+                        float t = tri_dist(p.o, p.d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
+                        if (t < best) {
+                            best = t;
+                            best_id = (int)rt_f2u(t1.w);
+                        }
+                        last = (rt_f2u(t0.w) & 1u) != 0u;
+                        cur = ~(k + 1);
+                    }
+                    if (last) {
+                        PT_POP();
+                    }
+                }
+            }
+        }
+#undef PT_POP
+    }
+    if (COUNT && a.counters) flush_counters6(cn, paths, a.counters);
+#ifdef PT_DIAG
+    if (a.counters)
+        for (int k = 0; k < 8; k++) {
+            unsigned long long x = dg[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((tid & 63) == 0) atomicAdd(&a.counters[8 + k], x);
+        }
+#endif
+#undef DIAG
+#undef PT_PUT
+#undef PT_GET
+}
+
+// Folds the staged samples of one batch into the framebuffer, frame by frame in order:
+// final = (acc*frameCount + colour) / (frameCount + 1)   (raytrace.glsl:296), or acc + colour in SUM mode.
+__global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint32_t num_frames, uint32_t pixels,
+                                                    uint32_t frame_base, uint32_t frame_stride, uint32_t sum_mode,
+                                                    uint32_t read_prev, const float4* prev, float4* out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pixels) return;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (read_prev) acc = prev[i];
+    for (uint32_t j = 0; j < num_frames; j++) {
+        float4 c = samples[(size_t)j * pixels + i];
+        uint32_t frame = frame_base + j * frame_stride;
+        float fc = (float)frame, fc1 = (float)(frame + 1u);
+        bool s = sum_mode != 0;
+        acc = make_float4(accumulate(acc.x, c.x, fc, fc1, s), accumulate(acc.y, c.y, fc, fc1, s),
+                          accumulate(acc.z, c.z, fc, fc1, s), accumulate(acc.w, c.w, fc, fc1, s));
+    }
+    out[i] = acc;
+}
+
+#endif  // RT_PATHS_H

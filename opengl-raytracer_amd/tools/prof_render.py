@@ -21,9 +21,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="time rt_primary_hits instead of full frames")
+    ap.add_argument("--counters", action="store_true", help="render with RT_FLAG_COUNTERS and print the work counters")
     a = ap.parse_args()
     pkg = entry.load_package()
     obj, pos = SCENES[a.scene]
@@ -31,7 +32,7 @@ def main():
     cam = pkg.make_camera(pos=pos)
     ctx = pkg.RenderContext(0)
     ctx.upload_scene(scene)
-    flags = (pkg.RT_FLAG_MEGAKERNEL if a.pipeline == "megakernel" else 0) | (pkg.RT_FLAG_FIX_INVDIR if a.fix_invdir else 0)
+    flags = {"paths": 0, "wavefront": pkg.RT_FLAG_WAVEFRONT, "megakernel": pkg.RT_FLAG_MEGAKERNEL}[a.pipeline] | (pkg.RT_FLAG_FIX_INVDIR if a.fix_invdir else 0)
     if a.primary_only:
         t0 = time.perf_counter()
         for _ in range(a.frames):
@@ -39,12 +40,16 @@ def main():
         print(f"primary_hits: {(time.perf_counter() - t0) / a.frames * 1e3:.3f} ms per call (incl. download)")
         return
     import numpy as np
+    if a.counters:
+        flags |= pkg.RT_FLAG_COUNTERS
     img = np.zeros((a.height, a.width, 4), dtype=np.float32)
     ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags), img)
     t0 = time.perf_counter()
     ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.frames, flags=flags), img)
     dt = time.perf_counter() - t0
     print(f"{a.pipeline} {a.scene} {a.width}x{a.height}: {dt / a.frames * 1e3:.3f} ms per frame over {a.frames} frames (incl. one download)")
+    if a.counters:
+        print("counters [box tri rays hits pops paths]:", ctx.counters().tolist())
     ctx.close()
 
 

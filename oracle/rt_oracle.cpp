@@ -59,6 +59,7 @@ struct PixelCounters {  // the shader's per-invocation globals, raytrace.glsl:58
     int numReflections = 0;
     // bookkeeping that is not in the shader
     unsigned long long rays = 0, hits = 0, pops = 0;
+    int maxStack = 0;  // deepest stack index the traversal wrote to
 };
 
 struct Scene {
@@ -161,6 +162,7 @@ HitInfo closest_hit(const Scene& sc, const Ray& ray, PixelCounters& pc) {
                     stack[++i] = child1;
                     dist[i] = d1;
                 }
+                if (i > pc.maxStack) pc.maxStack = i;
             } else {
                 if (d1 < info.dist) {
                     stack[++i] = child1;
@@ -170,6 +172,7 @@ HitInfo closest_hit(const Scene& sc, const Ray& ray, PixelCounters& pc) {
                     stack[++i] = child2;
                     dist[i] = d2;
                 }
+                if (i > pc.maxStack) pc.maxStack = i;
             }
         }
     }
@@ -410,7 +413,7 @@ void oracle_primary_hits(const rt_scene* s, const rt_camera* cam, int width, int
 // its most expensive ray, and total node pops.
 void oracle_path_stats(const rt_scene* s, const float* normals, const rt_camera* cam, const rt_params* p,
                        uint32_t frame_count, uint32_t* out_rays, uint32_t* out_max_pops, uint32_t* out_pops,
-                       int num_threads) {
+                       uint32_t* out_max_stack, int num_threads) {
     Scene sc = make_scene(s, normals);
     float pw = pixel_width(cam, p->width);
     bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
@@ -431,6 +434,8 @@ void oracle_path_stats(const rt_scene* s, const float* normals, const rt_camera*
                 rays++;
                 pops += (uint32_t)pc.pops;
                 if (pc.pops > maxp) maxp = (uint32_t)pc.pops;
+                if (out_max_stack && (uint32_t)pc.maxStack > out_max_stack[(size_t)gy * p->width + gx])
+                    out_max_stack[(size_t)gy * p->width + gx] = (uint32_t)pc.maxStack;
                 if (!(info.dist < RT_INF)) break;
                 ray.origin = rt_add(ray.origin, rt_scale(ray.dir, info.dist));
                 rt_vec3 normal = load3(sc.normals, info.triangleIndex);

@@ -70,13 +70,17 @@ def test_primary_hits_bit_exact(pkg, oracle, gpu_ctx, scenes, name, size):
     assert np.array_equal(bits(t), bits(t_o))
 
 
-@pytest.mark.parametrize("flags_name", ["wavefront", "megakernel"])
+def _pipeline_flags(pkg, name):
+    return {"paths": 0, "wavefront": pkg.RT_FLAG_WAVEFRONT, "megakernel": pkg.RT_FLAG_MEGAKERNEL}[name]
+
+
+@pytest.mark.parametrize("flags_name", ["paths", "wavefront", "megakernel"])
 @pytest.mark.parametrize("name", ["teapot", "dragon80k"])
 def test_frame0_full_size(pkg, oracle, gpu_ctx, scenes, name, flags_name):
     """BASELINE configs[0]/[1]: 1920x1080, 1 spp, 100 bounces, Russian roulette, bug-compatible."""
     scene = scenes(name)
     cam = pkg.make_camera(**CAMERAS[name])
-    flags = pkg.RT_FLAG_COUNTERS | (pkg.RT_FLAG_MEGAKERNEL if flags_name == "megakernel" else 0)
+    flags = pkg.RT_FLAG_COUNTERS | _pipeline_flags(pkg, flags_name)
     params = pkg.make_params(1920, 1080, flags=flags)
     gpu_ctx.upload_scene(scene)
     gpu_ctx.reset_counters()
@@ -91,7 +95,10 @@ def test_frame0_full_size(pkg, oracle, gpu_ctx, scenes, name, flags_name):
 
 @pytest.mark.parametrize("variant", [
     dict(frames=4),
+    dict(frames=11),                      # more than one batch of the persistent kernel
+    dict(frames=4, flags="wave"),
     dict(frames=3, flags="fix"),
+    dict(frames=3, flags="wave+fix"),
     dict(frames=2, flags="mega"),
     dict(frames=2, flags="mega+fix"),
     dict(frames=2, rays_per_pixel=3),
@@ -99,6 +106,9 @@ def test_frame0_full_size(pkg, oracle, gpu_ctx, scenes, name, flags_name):
     dict(frames=1, ray_bounces=1),
     dict(frames=1, ray_bounces=0),
     dict(frames=1, ray_bounces=5, flags="fix"),
+    dict(frames=2, ray_bounces=3, flags="wave"),
+    dict(frames=1, ray_bounces=2, flags="wave"),
+    dict(frames=3, flags="wave+sum", frame_stride=2, frame_base=0),
     dict(frames=1, render_mode=2),
     dict(frames=1, render_mode=3),
     dict(frames=1, render_mode=4),
@@ -114,6 +124,8 @@ def test_variants_small(pkg, oracle, gpu_ctx, scenes, name, size, variant):
         flags |= pkg.RT_FLAG_FIX_INVDIR
     if "mega" in fl:
         flags |= pkg.RT_FLAG_MEGAKERNEL
+    if "wave" in fl:
+        flags |= pkg.RT_FLAG_WAVEFRONT
     if "sum" in fl:
         flags |= pkg.RT_FLAG_SUM
     scene = scenes(name)
