@@ -526,7 +526,7 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     if (want_spill > c->pspill_entries) {
         dfree(c->d_pspill);
         c->pspill_entries = 0;
-        HIPCHK(c, hipMalloc(&c->d_pspill, want_spill * (size_t)c->num_cus * PT_BLOCK * sizeof(uint2)));
+        HIPCHK(c, hipMalloc(&c->d_pspill, want_spill * (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK * sizeof(uint2)));
         c->pspill_entries = want_spill;
     }
     return RT_OK;
@@ -560,9 +560,9 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }
     a.samples = c->d_samples;
     a.spill = c->d_pspill;
-    a.spill_stride = (size_t)c->num_cus * PT_BLOCK;
+    a.spill_stride = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
     a.counters = count ? c->d_counters : nullptr;
-    dim3 grid(c->num_cus), blk(PT_BLOCK);
+    dim3 grid(c->num_cus * PT_BLOCKS_PER_CU), blk(PT_BLOCK);
     {
         LaunchTimer lt(c, RT_K_PATHS);
 #define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, c->stream, c->sc, dc, a)
@@ -600,9 +600,9 @@ int rt_create(int device_id, rt_context** out_ctx) {
     rt_context* c = new rt_context();
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreate(&c->own_stream)) != hipSuccess ||
-        (e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&c->d_counts, 64 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMemset(c->d_counters, 0, 16 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemset(c->d_counters, 0, 32 * sizeof(unsigned long long))) != hipSuccess) {
         int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
         delete c;
         return rc;
@@ -733,8 +733,8 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
         if (!order[i].leaf && rec_of[i] < 0) rec_of[i] = next_rec++;
     // Pass 3: fill the records.
     std::vector<float> recs((size_t)num_inner * 16, 0.0f);  // 16 floats per inner node
-    std::vector<float> tris;                                 // 12 floats per leaf-ordered triangle
-    tris.reserve((size_t)T * 12);
+    std::vector<float> tris;                                 // 16 floats per leaf-ordered triangle
+    tris.reserve((size_t)T * 16);
     int root_ref = 0;
     auto as_f = [](int v) { return rt_u2f((uint32_t)v); };
     for (int i = 0; i < V; i++) {
@@ -744,15 +744,16 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
             if (v.b < v.a) {
                 ref = RT_REF_EMPTY;
             } else {
-                ref = ~(int)(tris.size() / 12);
+                ref = ~(int)(tris.size() / 16);
                 for (int k = v.a; k <= v.b; k++) {
                     const float *p0 = s->triv0 + 4 * (size_t)k, *p1 = s->triv1 + 4 * (size_t)k, *p2 = s->triv2 + 4 * (size_t)k;
-                    float rec[12] = {p0[0], p0[1], p0[2], as_f(k == v.b ? 1 : 0),
+                    float rec[16] = {p0[0], p0[1], p0[2], as_f(k == v.b ? 1 : 0),
                                      p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], as_f(k),
-                                     p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f};
-                    tris.insert(tris.end(), rec, rec + 12);
+                                     p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f,
+                                     0.0f, 0.0f, 0.0f, 0.0f};
+                    tris.insert(tris.end(), rec, rec + 16);
                 }
-                if (tris.size() / 12 > (size_t)0x7ffffff0) return fail(c, RT_ELIMIT, "too many triangle records");
+                if (tris.size() / 16 > (size_t)0x7ffffff0) return fail(c, RT_ELIMIT, "too many triangle records");
             }
         } else {
             ref = rec_of[i];
@@ -773,12 +774,12 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
-    size_t nrec = recs.size() / 16, ntri = tris.size() / 12;
+    size_t nrec = recs.size() / 16, ntri = tris.size() / 16;
     HIPCHK(c, hipMalloc(&c->d_nodes, (nrec ? nrec : 1) * 16 * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->d_tris, (ntri ? ntri : 1) * 12 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->d_tris, (ntri ? ntri : 1) * 16 * sizeof(float)));
     HIPCHK(c, hipMalloc(&c->d_shade, (size_t)T * 2 * sizeof(float4)));
     if (nrec) HIPCHK(c, hipMemcpyAsync(c->d_nodes, recs.data(), nrec * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (ntri) HIPCHK(c, hipMemcpyAsync(c->d_tris, tris.data(), ntri * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (ntri) HIPCHK(c, hipMemcpyAsync(c->d_tris, tris.data(), ntri * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     // the normals kernel reads the caller's vertex arrays as the reference's does (normals.glsl:15-17)
     float4 *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *col = nullptr;
     size_t vb = (size_t)T * sizeof(float4);
@@ -995,7 +996,7 @@ int rt_counters(rt_context* c, uint64_t out[RT_NUM_COUNTERS]) {
     for (int k = 0; k < RT_NUM_COUNTERS; k++) out[k] = tmp[k];
 #ifdef PT_DIAG
     {
-        unsigned long long d[8];
+        unsigned long long d[12];
         (void)hipMemcpy(d, c->d_counters + 8, sizeof d, hipMemcpyDeviceToHost);
         fprintf(stderr, "PT_DIAG inner iters %llu lanes/iter %.2f | leaf phases %llu lanes/phase %.2f | service iters %llu lanes/iter %.2f | tri iters %llu lanes/iter %.2f\n",
                 d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[2], d[2] ? (double)d[3] / d[2] : 0.0, d[4], d[4] ? (double)d[5] / d[4] : 0.0,
@@ -1007,7 +1008,7 @@ int rt_counters(rt_context* c, uint64_t out[RT_NUM_COUNTERS]) {
 
 int rt_reset_counters(rt_context* c) {
     if (!c) return RT_EINVAL;
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 

@@ -17,7 +17,8 @@
 //            q2 = (c2.min.z c2.max.x c2.max.y c2.max.z)   q3 = (ref1 ref2 - -) as int bits
 //          ref >= 0: inner record index; ref < 0: leaf, first triangle record = ~ref;
 //          ref == RT_REF_EMPTY: leaf with an empty range.
-//   tris   one 48-byte record per triangle, in leaf order:
+//   tris   one 64-byte record per triangle (48 used; padded so a record never straddles a cache line),
+//          in leaf order:
 //            q0 = (a.xyz, flags) flags bit0 = last triangle of its leaf
 //            q1 = (b-a, id)      id = index in the caller's triangle arrays (what hits report)
 //            q2 = (c-a, 0)       the edges are the reference's own first two subtractions (:85-86)
@@ -146,7 +147,7 @@ __device__ __forceinline__ void closest_hit(const DScene& sc, rt_vec3 o, rt_vec3
         } else if (cur != RT_REF_EMPTY) {
             int k = ~cur;
             for (;;) {
-                const float4* tr = sc.tris + (size_t)k * 3;
+                const float4* tr = sc.tris + (size_t)k * 4;
                 float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
                 if (COUNT) cn.tri++;
                 float t = tri_dist(o, d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));

@@ -28,11 +28,14 @@
 
 #include "rt_device.h"
 
-#define PT_BLOCK 1024
-#define PT_STACK 12
-#define PT_CACHE 1000          // inner-node records staged in LDS (64 B each)
-#define PT_MIN_TRAV 24         // leave the traversal phase when fewer lanes than this still traverse ...
-#define PT_MIN_SERVICE 8       // ... and keep servicing only while at least this many lanes need it
+#ifndef PT_BLOCK
+#define PT_BLOCK 768           // threads per workgroup (12 waves)
+#define PT_BLOCKS_PER_CU 2     // -> 24 waves per CU, 6 per SIMD (needs <= 80 VGPRs)
+#define PT_STACK 8             // traversal-stack entries per lane kept in LDS
+#define PT_CACHE 511           // inner-node records staged in LDS (64 B each); 2 x (stacks+cache+counter) <= 160 KiB
+#endif
+#define PT_MIN_TRAV 40         // leave the traversal phase when fewer lanes than this still traverse ...
+#define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
 #define PT_MAX_BATCH 8         // frames per launch
 
 enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
@@ -78,7 +81,7 @@ __device__ __forceinline__ uint2 spill_load(const uint2* p) {
 }
 
 template <bool COUNT, bool FIX>
-__global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, PathsArgs a) {
+__global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k_paths(DScene sc, DCamera cam, PathsArgs a) {
     __shared__ uint2 s_stack[PT_STACK][PT_BLOCK];
     __shared__ float4 s_nodes[PT_CACHE * 4];
     __shared__ uint32_t s_next;
@@ -131,12 +134,17 @@ __global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, Path
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // iteration counters (even k): only the first active lane counts; lane sums (odd k): every active lane adds 1
 #define DIAG(k_, v_) dg[k_] += ((k_) & 1) ? 1ull : (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u ? 1ull : 0ull)
+#define STAMP(var_)
+#define STAMP_ADD(k_, from_)
 #else
 #define DIAG(k_, v_)
+#define STAMP(var_)
+#define STAMP_ADD(k_, from_)
 #endif
 
     for (;;) {
         // ------------------------------------------------------------------ service phase
+        STAMP(ts0);
         for (;;) {
             DIAG(4, 1);
             if (state == ST_DONE || (state == ST_NEED && !exhausted)) { DIAG(5, 1); }
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, Path
             if (__popcll(pending) < a.min_service && __ballot(state == ST_TRAV) != 0ull) break;
         }
 
+        STAMP_ADD(0, ts0);
         if (__ballot(state == ST_TRAV) == 0ull) {
             // nothing traverses: either everything is finished or only stragglers wait for service
             if (__ballot(state == ST_DONE || (state == ST_NEED && !exhausted)) == 0ull) break;
@@ -240,13 +249,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, Path
         }                                                    \
     }
         for (;;) {
+            STAMP(th0);
             const bool want_inner = state == ST_TRAV && cur >= 0;
             const bool want_leaf = state == ST_TRAV && cur < 0;
             const unsigned long long mi = __ballot(want_inner), ml = __ballot(want_leaf);
             const int ni = __popcll(mi), nl = __popcll(ml);
             if (ni + nl == 0) break;
             if (ni + nl < a.min_trav && __ballot(state == ST_DONE || (state == ST_NEED && !exhausted)) != 0ull) break;
+            STAMP_ADD(3, th0);
             if (ni >= nl) {
+                STAMP(ti0);
                 if (want_inner) {
                     DIAG(0, 1);
                     DIAG(1, 1);
@@ -301,14 +313,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, Path
                         PT_POP();
                     }
                 }
+                STAMP_ADD(1, ti0);
             } else {
+                STAMP(tt0);
                 if (want_leaf) {
                     DIAG(6, 1);
                     DIAG(7, 1);
                     bool last = true;
                     if (cur != RT_REF_EMPTY) {
                         const int k = ~cur;
-                        const float4* tr = sc.tris + (size_t)k * 3;
+                        const float4* tr = sc.tris + (size_t)k * 4;
                         float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
                         if (COUNT) cn.tri++;
                         float t = tri_dist(p.o, p.d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
@@ -323,6 +337,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, Path
                         PT_POP();
                     }
                 }
+                STAMP_ADD(2, tt0);
             }
         }
 #undef PT_POP
@@ -335,6 +350,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_paths(DScene sc, DCamera cam, Path
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((tid & 63) == 0) atomicAdd(&a.counters[8 + k], x);
         }
+
 #endif
 #undef DIAG
 #undef PT_PUT
