@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 39.3 T fp32 lane-ops/s (FMA counted once)
 WORKLOADS = {
     # name: (obj, camera position, width, height)
     "dragon80k_1080p": ("dragon80k.obj", (0.0, 0.0, -5.5), 1920, 1080),
@@ -47,6 +48,13 @@ def algorithmic_bytes(c) -> float:
     write).  c = [box, tri, rays, hits, pops, paths]."""
     box, tri, rays, hits, pops, paths = [float(x) for x in c]
     return 32.0 * box + 16.0 * pops + 48.0 * tri + 32.0 * hits + 32.0 * paths
+
+
+def algorithmic_lane_ops(c) -> float:
+    """VALU view of the same counters: ~27 lane-ops per box test (6 sub, 6 mul, 12 min/max, 3 compares),
+    ~60 per triangle test (two cross products, four dots, a division), ~150 per ray for shading."""
+    box, tri, rays, hits, pops, paths = [float(x) for x in c]
+    return 27.0 * box + 60.0 * tri + 150.0 * rays
 
 
 def main() -> int:
@@ -83,6 +91,7 @@ def main() -> int:
     dev = torch.device("cuda", local_rank)
 
     pkg = entry.load_package()
+    from opengl_raytracer_amd import partition
     obj, cam_pos, W, H = WORKLOADS[args.workload]
     scene = pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1)
     cam = pkg.make_camera(pos=cam_pos)
@@ -104,8 +113,8 @@ def main() -> int:
     def render_steps(first_step: int, nsteps: int, flags: int, target, bounces: int = 100):
         """nsteps steps of this rank (frameCount (first_step+k)*world + rank) in ONE call of the boundary:
         the library is free to render the frames of a call concurrently."""
-        p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=first_step * world + rank, frames=nsteps,
-                            frame_stride=world, flags=flags)
+        base, stride, n = partition.rank_frames(rank, world, first_step, nsteps)
+        p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=base, frames=n, frame_stride=stride, flags=flags)
         ctx.render_device(cam, p, target.data_ptr())
 
     def barrier():
@@ -231,6 +240,13 @@ def main() -> int:
                 "traffic": traffic,
                 "launch_ms": round(dom_ms, 4),
                 "algorithmic_bytes_per_launch": round(dom_bytes_per_launch, 0),
+                "note": "scene is L2/Infinity-Cache resident, so algorithmic bytes/s may exceed the HBM peak; "
+                        "the binding ceiling is VALU issue (see alu)",
+                "alu": {
+                    "achieved_lane_ops_per_s": round(algorithmic_lane_ops(counters_all) / elapsed, 0),
+                    "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                    "frac": round(algorithmic_lane_ops(counters_all) / elapsed / VALU_PEAK_LANE_OPS / world, 4),
+                },
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,178 @@
+// Headless driver with the loop semantics of the reference's main.cpp:183-203, without a window:
+//   * camera = yRotation(yaw) * xRotation(pitch) (main.cpp:41-51), pitch clamped to +-pi/2, WASD moves along the
+//     camera axes at CAMERA_MOVE_SPEED units per second (main.cpp:216-231) -- driven by a script instead of GLFW;
+//   * any input resets frameCount to 0 (main.cpp:184-188), otherwise frames accumulate through two ping-pong
+//     frame buffers (main.cpp:189-201);
+//   * "Raytracer initialised in ... seconds" and "Average FPS" are printed as the reference prints them.
+// Display, where wanted, is a plain download of the frame; here the last frame is written as PFM/PPM (the image
+// is stored bottom row first, as GL textures are; PFM keeps that order, PPM is flipped).
+//
+// usage: rt_headless <scene.obj> [--size W H] [--frames N] [--pos x y z] [--pitch p] [--yaw y] [--mode 1..4]
+//                    [--script "w:0.5,a:0.2,yaw:0.1,pitch:-0.2,wait:8;..."] [--batch] [--out image.pfm|.ppm]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "raytrace.h"
+#include "rt_host.h"
+
+struct Step {
+    float w = 0, a = 0, s = 0, d = 0;  // seconds each key is held
+    double dyaw = 0, dpitch = 0;       // mouse look (radians)
+    int wait = 1;                      // frames rendered after this input
+};
+
+static std::vector<Step> parse_script(const std::string& text) {
+    std::vector<Step> out;
+    std::stringstream all(text);
+    std::string item;
+    while (std::getline(all, item, ';')) {
+        Step st;
+        std::stringstream one(item);
+        std::string kv;
+        while (std::getline(one, kv, ',')) {
+            auto c = kv.find(':');
+            if (c == std::string::npos) continue;
+            std::string k = kv.substr(0, c);
+            double v = std::atof(kv.substr(c + 1).c_str());
+            if (k == "w") st.w = (float)v;
+            else if (k == "a") st.a = (float)v;
+            else if (k == "s") st.s = (float)v;
+            else if (k == "d") st.d = (float)v;
+            else if (k == "yaw") st.dyaw = v;
+            else if (k == "pitch") st.dpitch = v;
+            else if (k == "wait") st.wait = std::max(1, (int)v);
+        }
+        out.push_back(st);
+    }
+    return out;
+}
+
+static Vec3 mat_mul(const Mat3& m, Vec3 v) {  // column-major mat3 * vec3
+    return {m[0] * v[0] + m[3] * v[1] + m[6] * v[2], m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+            m[2] * v[0] + m[5] * v[1] + m[8] * v[2]};
+}
+
+static void write_image(const std::string& path, const std::vector<float>& rgba, int w, int h) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    bool pfm = path.size() > 4 && path.substr(path.size() - 4) == ".pfm";
+    if (pfm) {
+        std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h);  // little endian, bottom row first (as stored)
+        for (int i = 0; i < w * h; i++) std::fwrite(&rgba[4 * (size_t)i], sizeof(float), 3, f);
+    } else {
+        std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+        for (int y = h - 1; y >= 0; y--)
+            for (int x = 0; x < w; x++)
+                for (int c = 0; c < 3; c++) {
+                    float v = std::min(1.0f, std::max(0.0f, rgba[4 * ((size_t)y * w + x) + c]));
+                    std::fputc((int)(v * 255.0f + 0.5f), f);
+                }
+    }
+    std::fclose(f);
+}
+
+#define HIP_OK(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: %s <scene.obj> [--size W H] [--frames N] [--pos x y z] [--pitch p] [--yaw y] "
+                             "[--mode m] [--script s] [--batch] [--out file]\n", argv[0]);
+        return 1;
+    }
+    std::string obj = argv[1], out_path, script;
+    int W = 1920, H = 1080, frames = 64, mode = RT_MODE_RENDER;
+    bool batch = false;
+    Vec3 cameraPos = CAMERA_START_POS;
+    double cameraPitch = 0.0, cameraYaw = 0.0;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) throw std::runtime_error("missing value after " + a); };
+        if (a == "--size") { need(2); W = std::atoi(argv[++i]); H = std::atoi(argv[++i]); }
+        else if (a == "--frames") { need(1); frames = std::atoi(argv[++i]); }
+        else if (a == "--pos") { need(3); for (int k = 0; k < 3; k++) cameraPos[k] = (float)std::atof(argv[++i]); }
+        else if (a == "--pitch") { need(1); cameraPitch = std::atof(argv[++i]); }
+        else if (a == "--yaw") { need(1); cameraYaw = std::atof(argv[++i]); }
+        else if (a == "--mode") { need(1); mode = std::atoi(argv[++i]); }
+        else if (a == "--script") { need(1); script = argv[++i]; }
+        else if (a == "--out") { need(1); out_path = argv[++i]; }
+        else if (a == "--batch") batch = true;
+    }
+    try {
+        SceneData* sceneData = loadScene(obj);
+        auto t0 = std::chrono::steady_clock::now();
+        Raytracer* rt = raytraceInit(sceneData, W, H);
+        std::cout << "Raytracer initialised in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()
+                  << " seconds" << std::endl;
+        size_t bytes = (size_t)W * H * 4 * sizeof(float);
+        float *currentFrame = nullptr, *prevFrame = nullptr;
+        HIP_OK(hipMalloc(&currentFrame, bytes));
+        HIP_OK(hipMalloc(&prevFrame, bytes));
+        HIP_OK(hipMemset(currentFrame, 0, bytes));
+        HIP_OK(hipMemset(prevFrame, 0, bytes));
+
+        std::vector<Step> steps = parse_script(script);
+        if (steps.empty()) steps.push_back(Step{0, 0, 0, 0, 0, 0, frames});
+        int frameCount = 0, totalFrames = 0;
+        Mat3 cameraRotation{};
+        std::cout << "BEGAN RENDER LOOP" << std::endl;
+        auto start = std::chrono::steady_clock::now();
+        for (size_t si = 0; si < steps.size(); si++) {
+            const Step& st = steps[si];
+            bool clearAccumulatedFrames = si > 0 || st.w || st.a || st.s || st.d || st.dyaw != 0 || st.dpitch != 0;
+            // processInput: translate along the camera axes with the rotation of the previous frame
+            cameraPos = {cameraPos[0], cameraPos[1], cameraPos[2]};
+            Vec3 mv = mat_mul(cameraRotation, {CAMERA_MOVE_SPEED * (st.d - st.a), 0.0f, CAMERA_MOVE_SPEED * (st.w - st.s)});
+            if (st.w || st.a || st.s || st.d) for (int k = 0; k < 3; k++) cameraPos[k] += mv[k];
+            // updateCameraRotation
+            cameraPitch = std::max(-M_PI / 2.0, std::min(M_PI / 2.0, cameraPitch + st.dpitch));
+            cameraYaw += st.dyaw;
+            rt_host_camera_rotation(cameraPitch, cameraYaw, cameraRotation.data());
+            if (clearAccumulatedFrames) frameCount = 0;
+            if (batch && mode == RT_MODE_RENDER) {
+                // same pixels, but the library may render the frames of one call concurrently
+                raytraceAccumulate(rt, cameraPos, cameraRotation, frameCount, st.wait, currentFrame);
+                frameCount += st.wait;
+                totalFrames += st.wait;
+            } else {
+                for (int f = 0; f < st.wait; f++) {
+                    raytrace(rt, cameraPos, cameraRotation, mode, frameCount, prevFrame, currentFrame);
+                    std::swap(currentFrame, prevFrame);
+                    frameCount++;
+                    totalFrames++;
+                }
+                std::swap(currentFrame, prevFrame);  // currentFrame = the frame written last
+            }
+        }
+        rt_synchronize(rt->ctx);
+        double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+        std::cout << "Average FPS: " << totalFrames / secs << "\n";
+        if (!out_path.empty()) {
+            std::vector<float> host((size_t)W * H * 4);
+            HIP_OK(hipMemcpy(host.data(), currentFrame, bytes, hipMemcpyDeviceToHost));
+            write_image(out_path, host, W, H);
+            std::cout << "wrote " << out_path << std::endl;
+        }
+        (void)hipFree(currentFrame);
+        (void)hipFree(prevFrame);
+        raytraceShutdown(rt);
+        delete sceneData;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 2;
+    }
+    return 0;
+}

@@ -1,0 +1,25 @@
+"""Sample partition of a progressive render over the GPUs of one node.
+
+The path shards by samples: the RNG seed is a pure function of (pixel, frameCount)
+(raytrace.glsl:277) and accumulation is a sum, so rank g of N renders frameCount g, g+N, g+2N, ...
+into a private SUM buffer (RT_FLAG_SUM, frame_stride = N); one reduce to rank 0 and a division by the
+total frame count give the image.  No collective is needed while rendering.
+"""
+from __future__ import annotations
+
+
+def rank_frames(rank: int, world: int, first_step: int, steps: int):
+    """(frame_base, frame_stride, frames) of `steps` steps of this rank starting at step `first_step`;
+    step s of rank g is frameCount s*world + g."""
+    if not (0 <= rank < world) or steps < 0 or first_step < 0:
+        raise ValueError("bad partition arguments")
+    return first_step * world + rank, world, steps
+
+
+def all_frames(world: int, first_step: int, steps: int):
+    """The frameCounts covered by all ranks together, for checking that the partition is exact."""
+    out = []
+    for g in range(world):
+        base, stride, n = rank_frames(g, world, first_step, steps)
+        out.extend(base + k * stride for k in range(n))
+    return sorted(out)

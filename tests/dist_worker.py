@@ -1,0 +1,45 @@
+"""Worker of tests/test_cpu_dist.py: one rank of a world-size-N gloo job rendering its share of the frames
+with the CPU oracle in SUM mode, reducing to rank 0 and checking against the sequential running mean."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    steps = int(sys.argv[1])
+    out_path = sys.argv[2]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = entry.load_package()
+    oracle = entry.load_oracle()
+    from opengl_raytracer_amd import partition
+
+    scene = pkg.load_scene(os.path.join(ROOT, "fixtures", "teapot.obj"), colour_seed=1)
+    cam = pkg.make_camera()
+    W, H = 96, 54
+    base, stride, n = partition.rank_frames(rank, world, 0, steps)
+    local = np.zeros((H, W, 4), dtype=np.float32)
+    p = pkg.make_params(W, H, frame_base=base, frame_stride=stride, frames=n, flags=pkg.RT_FLAG_SUM)
+    local, cnt = oracle.render(scene, cam, p, local, threads=2)
+    t = torch.from_numpy(local)
+    dist.reduce(t, dst=0)
+    rays = torch.tensor([float(cnt[2])], dtype=torch.float64)
+    dist.all_reduce(rays)
+    if rank == 0:
+        image = t.numpy() / float(steps * world)
+        want, cnt_all = oracle.render(scene, cam, pkg.make_params(W, H, frames=steps * world), threads=2)
+        err = float(np.sqrt(((image[..., :3] - want[..., :3]) ** 2).sum() / (want[..., :3] ** 2).sum()))
+        np.savez(out_path, err=err, rays=float(rays.item()), rays_seq=float(cnt_all[2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

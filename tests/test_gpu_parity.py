@@ -205,3 +205,33 @@ def test_render_without_scene_fails(pkg):
     with pytest.raises(RuntimeError, match="no scene"):
         ctx.render(pkg.make_camera(), pkg.make_params(64, 64))
     ctx.close()
+
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = [int(x) for x in f.readline().split()]
+        assert float(f.readline()) < 0
+        return np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_headless_driver_loop_semantics(pkg, oracle, scenes, tmp_path, batch):
+    """The C++ host mirror (host/rt_headless): scripted camera input resets the accumulation, frames
+    accumulate through ping-pong buffers, and the dumped image equals the oracle's for the final camera."""
+    import os
+    import subprocess
+    from conftest import ROOT, FIXTURES
+    exe = os.path.join(ROOT, "opengl-raytracer_amd", "host", "rt_headless")
+    if not os.path.exists(exe):
+        pytest.skip("host/rt_headless not built")
+    out = tmp_path / "frame.pfm"
+    cmd = [exe, os.path.join(FIXTURES, "teapot.obj"), "--size", "320", "180", "--script", "wait:3;yaw:0.2,w:0.5,wait:2",
+           "--out", str(out)] + (["--batch"] if batch else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Average FPS" in r.stdout and "Raytracer initialised" in r.stdout
+    got = _read_pfm(out)
+    cam = pkg.make_camera(pos=(0.0, 0.0, -1.0), yaw=0.2)   # W held 0.5 s at 2 units/s along the old view axis
+    want, _ = oracle.render(scenes("teapot"), cam, pkg.make_params(320, 180, frames=2))
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
