@@ -126,7 +126,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     p.o = p.d = p.inv = p.thr = rt_v3(0.0f, 0.0f, 0.0f);
     p.seed = 0;
     uint32_t out_idx = 0, bnc = 0;
-    int cur = 0, sp = 0, best_id = -1;
+    int cur = RT_REF_IDLE, sp = 0, best_id = -1;
     float best = RT_INF;
     Counters cn = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
@@ -134,17 +134,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // iteration counters (even k): only the first active lane counts; lane sums (odd k): every active lane adds 1
 #define DIAG(k_, v_) dg[k_] += ((k_) & 1) ? 1ull : (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u ? 1ull : 0ull)
-#define STAMP(var_)
-#define STAMP_ADD(k_, from_)
 #else
 #define DIAG(k_, v_)
-#define STAMP(var_)
-#define STAMP_ADD(k_, from_)
 #endif
 
     for (;;) {
         // ------------------------------------------------------------------ service phase
-        STAMP(ts0);
         for (;;) {
             DIAG(4, 1);
             if (state == ST_DONE || (state == ST_NEED && !exhausted)) { DIAG(5, 1); }
@@ -167,7 +162,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     state = ST_NEED;
                 }
             }
-            unsigned long long need = __ballot(state == ST_NEED);
+            const unsigned long long need = __builtin_amdgcn_ballot_w64(state == ST_NEED);
             if (need != 0ull && !exhausted) {
                 if (tile_off >= 64) {
                     uint32_t k = 0;
@@ -196,7 +191,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                             if (COUNT) paths++;
                         }
                     }
-                    int taken = __popcll(need);
+                    int taken = __builtin_popcountll(need);
                     tile_off += taken < avail ? taken : avail;
                 }
             }
@@ -218,17 +213,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     state = ST_TRAV;
                 }
             }
-            unsigned long long pending = __ballot(state == ST_DONE || (state == ST_NEED && !exhausted));
+            const unsigned long long pending = __builtin_amdgcn_ballot_w64(state == ST_DONE || (state == ST_NEED && !exhausted));
             if (pending == 0ull) break;
-            if (__popcll(pending) < a.min_service && __ballot(state == ST_TRAV) != 0ull) break;
+            if (__builtin_popcountll(pending) < a.min_service && __builtin_amdgcn_ballot_w64(cur != RT_REF_IDLE) != 0ull) break;
         }
 
-        STAMP_ADD(0, ts0);
-        if (__ballot(state == ST_TRAV) == 0ull) {
-            // nothing traverses: either everything is finished or only stragglers wait for service
-            if (__ballot(state == ST_DONE || (state == ST_NEED && !exhausted)) == 0ull) break;
-            continue;
-        }
+        if (__builtin_amdgcn_ballot_w64(cur != RT_REF_IDLE) == 0ull) break;  // nothing traverses, nothing left to serve
 
         // ------------------------------------------------------------------ traversal phase
         // Every iteration runs ONE kind of step -- an inner-node visit or a triangle test -- chosen by
@@ -237,6 +227,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     for (;;) {                                               \
         if (sp == 0) {                                       \
             state = ST_DONE;                                 \
+            cur = RT_REF_IDLE;                               \
             break;                                           \
         }                                                    \
         sp--;                                                \
@@ -249,16 +240,18 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
         }                                                    \
     }
         for (;;) {
-            STAMP(th0);
-            const bool want_inner = state == ST_TRAV && cur >= 0;
-            const bool want_leaf = state == ST_TRAV && cur < 0;
-            const unsigned long long mi = __ballot(want_inner), ml = __ballot(want_leaf);
-            const int ni = __popcll(mi), nl = __popcll(ml);
+            // idle lanes hold cur == RT_REF_IDLE (INT_MIN): inner <=> cur >= 0, leaf <=> cur in (INT_MIN, -1]
+            const bool want_inner = cur >= 0;
+            const bool want_leaf = (uint32_t)cur > 0x80000000u;
+            const unsigned long long mi = __builtin_amdgcn_ballot_w64(want_inner), ml = __builtin_amdgcn_ballot_w64(want_leaf);
+            const uint32_t ni = (uint32_t)__builtin_popcountll(mi), nl = (uint32_t)__builtin_popcountll(ml);
             if (ni + nl == 0) break;
-            if (ni + nl < a.min_trav && __ballot(state == ST_DONE || (state == ST_NEED && !exhausted)) != 0ull) break;
-            STAMP_ADD(3, th0);
+            if (ni + nl < (uint32_t)a.min_trav) {
+                // is there anything the service phase could do for the lanes that do not traverse?
+                const bool serviceable = exhausted ? __builtin_amdgcn_ballot_w64(state == ST_DONE) != 0ull : true;
+                if (serviceable) break;
+            }
             if (ni >= nl) {
-                STAMP(ti0);
                 if (want_inner) {
                     DIAG(0, 1);
                     DIAG(1, 1);
@@ -268,7 +261,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     // 13 memory instructions per visit instead of 4.)
                     f4 q0, q1, q2, q3;
                     {
-                        const unsigned long long staged = __ballot(cur < a.cache_recs);
+                        const unsigned long long staged = __builtin_amdgcn_ballot_w64(cur < a.cache_recs);
                         const uint32_t cc = (uint32_t)cur;
                         const uint32_t base = nodes_lds + (cc << 6), x = (cc >> 2) & 3u;
                         const float4* rec = sc.nodes + (size_t)cc * 4;
@@ -313,9 +306,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         PT_POP();
                     }
                 }
-                STAMP_ADD(1, ti0);
             } else {
-                STAMP(tt0);
                 if (want_leaf) {
                     DIAG(6, 1);
                     DIAG(7, 1);
@@ -337,7 +328,6 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         PT_POP();
                     }
                 }
-                STAMP_ADD(2, tt0);
             }
         }
 #undef PT_POP
@@ -350,6 +340,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((tid & 63) == 0) atomicAdd(&a.counters[8 + k], x);
         }
+
 
 #endif
 #undef DIAG
