@@ -38,6 +38,8 @@ WORKLOADS = {
     "dragon80k_1080p": ("dragon80k.obj", (0.0, 0.0, -5.5), 1920, 1080),
     "teapot_1080p": ("teapot.obj", (0.0, 0.0, -2.0), 1920, 1080),
     "dragon80k_4k": ("dragon80k.obj", (0.0, 0.0, -5.5), 3840, 2160),
+    # ~10M-triangle stress scene: baked grid of dragon stand-ins and teapots (generated in memory, ~15 s)
+    "grid9m_1080p": (None, (0.0, 0.0, -30.0), 1920, 1080),
 }
 
 
@@ -93,7 +95,16 @@ def main() -> int:
     pkg = entry.load_package()
     from opengl_raytracer_amd import partition
     obj, cam_pos, W, H = WORKLOADS[args.workload]
-    scene = pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1)
+    if obj is None:
+        sys.path.insert(0, os.path.join(ROOT, "opengl-raytracer_amd", "tools"))
+        import gen_scenes
+
+        fx = os.path.join(ROOT, "fixtures")
+        v, f = gen_scenes.grid([os.path.join(fx, "dragon80k.obj")] * 3 + [os.path.join(fx, "teapot.obj")], (6, 5, 5), 8.0, 7)
+        scene = pkg.build_scene(v, f, colour_seed=1)
+        obj = "generated grid 6x5x5 of dragon80k/teapot"
+    else:
+        scene = pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1)
     cam = pkg.make_camera(pos=cam_pos)
     ctx = pkg.RenderContext(local_rank)
     ctx.upload_scene(scene)
@@ -212,7 +223,7 @@ def main() -> int:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: fixtures/{obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
+                "workload": f"{args.workload}: {obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
                             f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
                             f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}",
                 "pipeline": args.pipeline,
