@@ -21,8 +21,10 @@
 //                      swizzled so that lanes reading different records spread over all 16-byte bank slots
 //   everything else    registers: ray, throughput, RNG state, pixel, bounce index, traversal cursor
 //
-// Samples go to a staging array [frame][pixel]; k_accumulate folds them into the framebuffer in frame order,
-// which keeps the running mean of raytrace.glsl:296 bit-exact although frames are rendered concurrently.
+// A finished path stores (throughput.rgb, dir.y) into a staging array [frame][pixel]; k_accumulate evaluates the
+// sky for it (densely, one lane per pixel, instead of on the few lanes of a wave that happen to finish together)
+// and folds the samples into the framebuffer in frame order, which keeps the running mean of raytrace.glsl:296
+// bit-exact although frames are rendered concurrently.
 #ifndef RT_PATHS_H
 #define RT_PATHS_H
 
@@ -144,7 +146,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             DIAG(4, 1);
             if (state == ST_DONE || (state == ST_NEED && !exhausted)) { DIAG(5, 1); }
             if (state == ST_DONE) {
-                rt_vec3 result = rt_v3(0.0f, 0.0f, 0.0f);
+                // sample = sky(dir.y) * throughput, evaluated by k_accumulate; a path that ends without
+                // reaching the sky (Russian roulette, bounce limit) contributes zero
+                float4 sample = make_float4(p.thr.x, p.thr.y, p.thr.z, p.d.y);
                 bool ended = true;
                 if (best < RT_INF) {
                     if (COUNT) cn.hits++;
@@ -154,11 +158,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         ended = false;
                         state = ST_NEW;
                     }
-                } else {
-                    result = rt_mul(sample_sky(p.d), p.thr);
+                    sample = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
                 if (ended) {
-                    a.samples[out_idx] = make_float4(result.x, result.y, result.z, 2.0f);
+                    a.samples[out_idx] = sample;
                     state = ST_NEED;
                 }
             }
@@ -358,7 +361,9 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint3
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (read_prev) acc = prev[i];
     for (uint32_t j = 0; j < num_frames; j++) {
-        float4 c = samples[(size_t)j * pixels + i];
+        float4 smp = samples[(size_t)j * pixels + i];
+        rt_vec3 sky = rt_mul(sample_sky(rt_v3(0.0f, smp.w, 0.0f)), rt_v3(smp.x, smp.y, smp.z));
+        float4 c = make_float4(sky.x, sky.y, sky.z, 2.0f);
         uint32_t frame = frame_base + j * frame_stride;
         float fc = (float)frame, fc1 = (float)(frame + 1u);
         bool s = sum_mode != 0;
