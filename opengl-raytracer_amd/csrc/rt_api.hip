@@ -28,9 +28,11 @@
 #include "rt_api.h"
 #include "rt_device.h"
 #include "rt_paths.h"
+#include "rt_paths2.h"
 
 #define RT_WF_BOUNCES 2       // bounces handled by wavefront kernels before the tail launch
 #define RT_TAIL_BLOCKS 1024   // grid of the tail kernel (grid-stride)
+#define RT_BFS_PREFIX (P2_CACHE > PT_CACHE ? P2_CACHE : PT_CACHE)  // inner-node records laid out breadth-first
 #define RT_MAX_DEPTH 126      // deepest tree accepted (the reference's own stack holds 128 entries)
 
 // ------------------------------------------------------------------------------------------------
@@ -374,6 +376,10 @@ struct rt_context {
     size_t samples_pixels = 0;
     uint2* d_pspill = nullptr;
     size_t pspill_entries = 0;
+    float4* d_queues = nullptr;   // wave-private READY/HIT queues of k_paths2
+    uint2* d_p2spill = nullptr;
+    size_t p2spill_entries = 0;
+    int use_paths2 = 0;  // RT_PATHS_GEN=2 selects the experimental second-generation kernel (rt_paths2.h)
 
     unsigned long long* d_counters = nullptr;
 
@@ -433,6 +439,9 @@ static void free_buffers(rt_context* c) {
     c->samples_pixels = 0;
     dfree(c->d_pspill);
     c->pspill_entries = 0;
+    dfree(c->d_queues);
+    dfree(c->d_p2spill);
+    c->p2spill_entries = 0;
 }
 
 // Brackets one launch with events when profiling is on.
@@ -551,7 +560,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     a.tiles_per_frame = a.tiles_x * ((p->height + 7) / 8);
     a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
     a.pixels = (uint32_t)pixels;
-    a.cache_recs = c->cache_recs;
+    a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
     a.min_trav = PT_MIN_TRAV;
     a.min_service = PT_MIN_SERVICE;
     // developer knobs for tuning runs
@@ -569,6 +578,65 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
         if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
         else { if (fix) PATHS(false, true); else PATHS(false, false); }
 #undef PATHS
+    }
+    HIPCHK(c, hipGetLastError());
+    {
+        LaunchTimer lt(c, RT_K_ACCUMULATE);
+        uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, c->stream,
+                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, frame_base, stride, sum ? 1u : 0u,
+                           read_prev, prev, out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+// Second-generation persistent kernel (rt_paths2.h): same contract as launch_paths_batch.
+static int launch_paths2_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
+                               uint32_t stride, uint32_t nframes, const float4* prev, float4* out) {
+    const bool sum = (p->flags & RT_FLAG_SUM) != 0;
+    const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
+    const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+    size_t pixels = (size_t)p->width * p->height;
+    int rc = ensure_paths_buffers(c, pixels);
+    if (rc != RT_OK) return rc;
+    const size_t lanes = (size_t)c->num_cus * P2_BLOCKS_PER_CU * P2_BLOCK;
+    if (!c->d_queues) {
+        HIPCHK(c, hipMalloc(&c->d_queues, (lanes / 64) * P2_QUEUE_FLOAT4_PER_WAVE * sizeof(float4)));
+    }
+    size_t want_spill = c->max_depth > P2_STACK ? (size_t)(c->max_depth - P2_STACK + 1) : 0;
+    if (want_spill > c->p2spill_entries) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dfree(c->d_p2spill);
+        c->p2spill_entries = 0;
+        HIPCHK(c, hipMalloc(&c->d_p2spill, want_spill * lanes * sizeof(uint2)));
+        c->p2spill_entries = want_spill;
+    }
+    Paths2Args a;
+    a.frame_base = frame_base;
+    a.frame_stride = stride;
+    a.num_frames = nframes;
+    a.bounces = p->ray_bounces;
+    a.tiles_x = (p->width + 7) / 8;
+    a.tiles_per_frame = a.tiles_x * ((p->height + 7) / 8);
+    a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
+    a.pixels = (uint32_t)pixels;
+    a.cache_recs = c->cache_recs < P2_CACHE ? c->cache_recs : P2_CACHE;
+    a.light = P2_LIGHT;
+    if (const char* e = getenv("RT_TUNE_LIGHT")) a.light = atoi(e);
+    if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }
+    a.samples = c->d_samples;
+    a.queues = c->d_queues;
+    a.spill = c->d_p2spill;
+    a.spill_stride = lanes;
+    a.counters = count ? c->d_counters : nullptr;
+    dim3 grid(c->num_cus * P2_BLOCKS_PER_CU), blk(P2_BLOCK);
+    {
+        LaunchTimer lt(c, RT_K_PATHS);
+#define PATHS2(C_, F_) hipLaunchKernelGGL((k_paths2<C_, F_>), grid, blk, 0, c->stream, c->sc, dc, a)
+        if (count) { if (fix) PATHS2(true, true); else PATHS2(true, false); }
+        else { if (fix) PATHS2(false, true); else PATHS2(false, false); }
+#undef PATHS2
     }
     HIPCHK(c, hipGetLastError());
     {
@@ -608,6 +676,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
         return rc;
     }
     c->stream = c->own_stream;
+    if (const char* e = getenv("RT_PATHS_GEN")) c->use_paths2 = atoi(e) == 2;
     hipDeviceProp_t prop;
     c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
                      ? prop.multiProcessorCount : 256;
@@ -717,11 +786,11 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     int next_rec = 0;
     {
         std::vector<int> level{0}, nxt;
-        while (!level.empty() && next_rec < PT_CACHE) {
+        while (!level.empty() && next_rec < RT_BFS_PREFIX) {
             nxt.clear();
             for (int i : level) {
                 if (order[i].leaf) continue;
-                if (next_rec < PT_CACHE) rec_of[i] = next_rec++;
+                if (next_rec < RT_BFS_PREFIX) rec_of[i] = next_rec++;
                 nxt.push_back(kids[2 * (size_t)i]);
                 nxt.push_back(kids[2 * (size_t)i + 1]);
             }
@@ -844,7 +913,8 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
     if (!mega && !wavefront)
-        return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame);
+        return c->use_paths2 ? launch_paths2_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame)
+                             : launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame);
     if ((rc = ensure_buffers(c, p->width, p->height)) != RT_OK) return rc;
 
     FrameArgs fa;
@@ -930,7 +1000,8 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     DCamera dc = make_dcamera(cam, p->width, p->height);
     for (uint32_t f = 0; f < p->frames; f += PT_MAX_BATCH) {
         uint32_t n = p->frames - f < PT_MAX_BATCH ? p->frames - f : PT_MAX_BATCH;
-        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum);
+        rc = c->use_paths2 ? launch_paths2_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum)
+                           : launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum);
         if (rc != RT_OK) return rc;
     }
     return RT_OK;
