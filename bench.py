@@ -81,7 +81,7 @@ def main() -> int:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             return 2
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run, also with a single rank
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

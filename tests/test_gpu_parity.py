@@ -235,3 +235,46 @@ def test_headless_driver_loop_semantics(pkg, oracle, scenes, tmp_path, batch):
     cam = pkg.make_camera(pos=(0.0, 0.0, -1.0), yaw=0.2)   # W held 0.5 s at 2 units/s along the old view axis
     want, _ = oracle.render(scenes("teapot"), cam, pkg.make_params(320, 180, frames=2))
     assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
+
+
+def test_config0_teapot_primary_plus_one_bounce(pkg, oracle, gpu_ctx, scenes):
+    """BASELINE configs[0]: teapot, 1920x1080, 1 spp, primary + 1 diffuse bounce (ray_bounces = 2)."""
+    scene = scenes("teapot")
+    cam = pkg.make_camera()
+    p = pkg.make_params(1920, 1080, ray_bounces=2, flags=pkg.RT_FLAG_COUNTERS)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.reset_counters()
+    got = gpu_ctx.render(cam, p)
+    cnt = gpu_ctx.counters()
+    want, cnt_o = oracle.render(scene, cam, p)
+    assert rrmse(got, want) <= RRMSE_TOL
+    _assert_image_equal(got, want, "teapot 2 bounces")
+    assert np.array_equal(cnt, cnt_o)
+
+
+def test_config2_4k_progressive_and_sample_partition(pkg, oracle, gpu_ctx, scenes):
+    """BASELINE configs[2]: dragon stand-in at 3840x2160, progressive accumulation, sample-partitioned.
+    Bit-exact against the oracle for the first two frames at full size; then the full 256 spp through
+    size-independent properties: (1) resuming in two halves equals one shot, (2) eight interleaved partial SUMs
+    divided by 256 equal the sequential running mean to fp32 rounding (the multi-GPU decomposition)."""
+    scene = scenes("dragon80k")
+    cam = pkg.make_camera(**CAMERAS["dragon80k"])
+    W, H = 3840, 2160
+    gpu_ctx.upload_scene(scene)
+    got = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2))
+    want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=2))
+    _assert_image_equal(got, want, "4K, 2 frames")
+    del want
+    full = gpu_ctx.render(cam, pkg.make_params(W, H, frames=256))
+    half = gpu_ctx.render(cam, pkg.make_params(W, H, frames=128))
+    half = gpu_ctx.render(cam, pkg.make_params(W, H, frames=128, frame_base=128), half)
+    assert np.array_equal(bits(full), bits(half))
+    total = np.zeros_like(full, dtype=np.float64)
+    G = 8
+    for g in range(G):
+        part = np.zeros_like(full)
+        total += gpu_ctx.render(cam, pkg.make_params(W, H, frames=256 // G, frame_base=g, frame_stride=G,
+                                                     flags=pkg.RT_FLAG_SUM), part)
+    # 256 running-mean updates in fp32 drift by ~2e-6 relative; the stated tolerance is 1e-3
+    assert rrmse((total / 256.0).astype(np.float32), full) < 1e-5
+    assert np.all(full[..., 3] == 2.0)
