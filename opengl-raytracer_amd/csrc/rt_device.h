@@ -109,6 +109,10 @@ __device__ __forceinline__ float tri_dist(rt_vec3 o, rt_vec3 d, rt_vec3 a, rt_ve
 // updates and the tie rule (d1 == d2 visits child 2 first) are the reference's; the nearer child is
 // continued with directly instead of being pushed and popped again, which is the same sequence.
 // best_id is the caller's triangle id or -1.
+//
+// All lanes that enter stay in the loop until the last one has finished: every iteration the wave runs
+// ONE kind of step -- inner-node visit or triangle test -- whichever more of its lanes wait for, under a
+// wave-uniform branch, instead of executing both bodies with complementary masks.
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DScene& sc, rt_vec3 o, rt_vec3 d, rt_vec3 inv, Stack st, float& best,
                                             int& best_id, Counters& cn) {
@@ -119,61 +123,81 @@ __device__ __forceinline__ void closest_hit(const DScene& sc, rt_vec3 o, rt_vec3
         cn.box++;
     }
     float d0 = box_dist(o, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2]);
-    if (d0 == RT_INF) return;
-    if (COUNT) cn.box++;  // the reference evaluates the root box a second time to seed the stack
-    int cur = sc.root_ref;
-    int sp = 0;  // entries currently on the stack
-    for (;;) {
-        // `cur` has just been popped and passed the cull
-        if (COUNT) cn.pops++;
-        bool descend = false;
-        if (cur >= 0) {
-            const float4* rec = sc.nodes + (size_t)cur * 4;
-            float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            if (COUNT) cn.box += 2;
-            float d1 = box_dist(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-            float d2 = box_dist(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-            int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
-            bool first_is_1 = d1 < d2;
-            int rn = first_is_1 ? r1 : r2, rf = first_is_1 ? r2 : r1;
-            float dn = first_is_1 ? d1 : d2, df = first_is_1 ? d2 : d1;
-            if (df < best) {
-                st.put(sp, rf, df);
-                sp++;
-            }
-            if (dn < best) {
-                cur = rn;
-                descend = true;
-            }
-        } else if (cur != RT_REF_EMPTY) {
-            int k = ~cur;
-            for (;;) {
-                const float4* tr = sc.tris + (size_t)k * 4;
-                float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
-                if (COUNT) cn.tri++;
-                float t = tri_dist(o, d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
-                if (t < best) {
-                    best = t;
-                    best_id = (int)rt_f2u(t1.w);
-                }
-                if (rt_f2u(t0.w) & 1u) break;
-                k++;
-            }
-        }
-        if (descend) continue;
-        // pop until an entry survives the cull
-        bool found = false;
-        while (sp > 0) {
-            sp--;
-            uint2 e = st.get(sp);
-            if (!(rt_u2f(e.y) >= best)) {
-                cur = (int)e.x;
-                found = true;
-                break;
-            }
-        }
-        if (!found) break;
+    int cur = RT_REF_IDLE;  // no node: the lane has finished
+    int sp = 0;             // entries currently on the stack
+    if (d0 != RT_INF) {
+        if (COUNT) cn.box++;  // the reference evaluates the root box a second time to seed the stack
+        cur = sc.root_ref;
+        if (COUNT && cur < 0) cn.pops++;
     }
+#define RT_POP()                                \
+    for (;;) {                                  \
+        if (sp == 0) {                          \
+            cur = RT_REF_IDLE;                  \
+            break;                              \
+        }                                       \
+        sp--;                                   \
+        uint2 e_ = st.get(sp);                  \
+        if (!(rt_u2f(e_.y) >= best)) {          \
+            cur = (int)e_.x;                    \
+            if (COUNT && cur < 0) cn.pops++;    \
+            break;                              \
+        }                                       \
+    }
+    for (;;) {
+        const bool want_inner = cur >= 0;
+        const bool want_leaf = (uint32_t)cur > 0x80000000u;
+        const uint32_t ni = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_inner));
+        const uint32_t nl = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(want_leaf));
+        if (ni + nl == 0u) break;
+        if (ni >= nl) {
+            if (want_inner) {
+                const float4* rec = sc.nodes + (size_t)cur * 4;
+                float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                if (COUNT) {
+                    cn.pops++;
+                    cn.box += 2;
+                }
+                float d1 = box_dist(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                float d2 = box_dist(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
+                bool first_is_1 = d1 < d2;
+                int rn = first_is_1 ? r1 : r2, rf = first_is_1 ? r2 : r1;
+                float dn = first_is_1 ? d1 : d2, df = first_is_1 ? d2 : d1;
+                if (df < best) {
+                    st.put(sp, rf, df);
+                    sp++;
+                }
+                if (dn < best) {
+                    cur = rn;
+                    if (COUNT && cur < 0) cn.pops++;
+                } else {
+                    RT_POP();
+                }
+            }
+        } else {
+            if (want_leaf) {
+                bool last = true;
+                if (cur != RT_REF_EMPTY) {
+                    const int k = ~cur;
+                    const float4* tr = sc.tris + (size_t)k * 4;
+                    float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
+                    if (COUNT) cn.tri++;
+                    float t = tri_dist(o, d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
+                    if (t < best) {
+                        best = t;
+                        best_id = (int)rt_f2u(t1.w);
+                    }
+                    last = (rt_f2u(t0.w) & 1u) != 0u;
+                    cur = ~(k + 1);
+                }
+                if (last) {
+                    RT_POP();
+                }
+            }
+        }
+    }
+#undef RT_POP
     if (COUNT && best_id >= 0) cn.hits++;
 }
 

@@ -178,3 +178,23 @@ def test_no_gpu_means_loud_failure(pkg):
         hip.rt_destroy(ctx)
     else:
         assert rc == -2 and b"no CPU path" in hip.rt_last_error(None)
+
+
+def test_compare_tool(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("compare_images", os.path.join(ROOT, "opengl-raytracer_amd", "tools", "compare_images.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    img = np.random.RandomState(0).uniform(0, 1, (9, 16, 3)).astype(np.float32)
+    p1, p2 = tmp_path / "a.pfm", tmp_path / "b.pfm"
+    for p, data in ((p1, img), (p2, img * np.float32(1.0005))):
+        with open(p, "wb") as f:
+            f.write(b"PF\n16 9\n-1.0\n")
+            f.write(data.astype("<f4").tobytes())
+    assert np.array_equal(m.read_pfm(str(p1)), img)
+    assert abs(m.rrmse(m.read_pfm(str(p2)), m.read_pfm(str(p1))) - 5e-4) < 1e-5
+    assert m.main([str(p2), str(p1)]) == 0 and m.main([str(p2), str(p1), "--tol", "1e-4"]) == 1
+    ids = np.array([[0, 1], [2, -1]]); t = np.array([[1.0, 2.0], [3.0, np.inf]], dtype=np.float32)
+    ids2 = np.array([[0, 5], [7, -1]]); t2 = np.array([[1.0, 2.0001], [3.5, np.inf]], dtype=np.float32)
+    r = m.compare_ids(ids, t, ids2, t2)
+    assert r["mismatch"] == 2 and r["epsilon_ties"] == 1 and r["real"] == 1
