@@ -278,3 +278,84 @@ def test_config2_4k_progressive_and_sample_partition(pkg, oracle, gpu_ctx, scene
     # 256 running-mean updates in fp32 drift by ~2e-6 relative; the stated tolerance is 1e-3
     assert rrmse((total / 256.0).astype(np.float32), full) < 1e-5
     assert np.all(full[..., 3] == 2.0)
+
+
+def _tiny_scene(pkg, tris, nodes=None):
+    """Scene from explicit triangles; nodes default to a single root leaf covering all of them."""
+    tris = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+    T = tris.shape[0]
+    pad = lambda v: np.concatenate([v, np.zeros((T, 1), np.float32)], axis=1)
+    if nodes is None:
+        lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+        nodes = np.array([[*lo, 0, *hi, 0, 1.0, 0.0, T - 1, 0]], dtype=np.float32)
+    return pkg.Scene(nodes, pad(tris[:, 0]), pad(tris[:, 1]), pad(tris[:, 2]), pkg.make_colours(5, T))
+
+
+@pytest.mark.parametrize("case", ["root_is_leaf", "empty_leaf", "degenerate_triangle", "nan_column"])
+@pytest.mark.parametrize("pipeline", ["paths", "wavefront", "megakernel"])
+def test_edge_scenes(pkg, oracle, gpu_ctx, case, pipeline):
+    """Ragged inputs: a tree that is a single leaf, a leaf with an empty triangle range (b < a), a degenerate
+    triangle (NaN normal, normals.glsl:18), and boxes ending exactly on the plane x = camera.x (0 * inf = NaN in
+    the slab test of the centre pixel column)."""
+    big = [[-3, -2, 5], [3, -2, 5], [0, 3, 6]]
+    if case == "root_is_leaf":
+        scene = _tiny_scene(pkg, [big])
+    elif case == "degenerate_triangle":
+        scene = _tiny_scene(pkg, [big, [[0, 0, 4], [0, 0, 4], [1, 1, 4]]])
+    elif case == "nan_column":
+        scene = _tiny_scene(pkg, [[[0, -2, 5], [3, -2, 5], [0, 3, 6]], [[-3, -2, 7], [0, -2, 7], [0, 3, 7]]])
+    else:
+        lo, hi = [-3, -2, 5], [3, 3, 6]
+        nodes = np.array([[*lo, 0, *hi, 0, 0.0, 1.0, 2.0, 0],      # root: children 1, 2
+                          [*lo, 0, *hi, 0, 1.0, 0.0, 0.0, 0],      # leaf with triangle 0
+                          [*lo, 0, *hi, 0, 1.0, 1.0, 0.0, 0]],     # leaf with the empty range [1, 0]
+                         dtype=np.float32)
+        scene = _tiny_scene(pkg, [big], nodes)
+    cam = pkg.make_camera(pos=(0.0, 0.0, -2.0))
+    flags = pkg.RT_FLAG_COUNTERS | _pipeline_flags(pkg, pipeline)
+    p = pkg.make_params(128, 96, frames=2, flags=flags)
+    gpu_ctx.upload_scene(scene)
+    gpu_ctx.reset_counters()
+    got = gpu_ctx.render(cam, p)
+    cnt = gpu_ctx.counters()
+    want, cnt_o = oracle.render(scene, cam, p)
+    same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), f"{int((~same).any(axis=-1).sum())} pixels differ"
+    assert np.array_equal(cnt, cnt_o)
+    ids, t = gpu_ctx.primary_hits(cam, 128, 96)
+    ids_o, t_o = oracle.primary_hits(scene, cam, 128, 96)
+    assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o))
+    assert (ids >= 0).any()
+
+
+def test_api_argument_errors(pkg, gpu_ctx, scenes):
+    import ctypes as C
+    lib = gpu_ctx.lib
+    gpu_ctx.upload_scene(scenes("model"))
+    cam = pkg.make_camera()
+    bad = [pkg.make_params(0, 10), pkg.make_params(10, -1), pkg.make_params(64, 64, rays_per_pixel=0),
+           pkg.make_params(64, 64, render_mode=9), pkg.make_params(20000, 20000)]
+    out = np.zeros((64, 64, 4), dtype=np.float32)
+    for p in bad:
+        rc = lib.rt_render(gpu_ctx.ctx, C.byref(cam), C.byref(p), pkg.fptr(out))
+        assert rc in (-1, -4) and len(lib.rt_last_error(gpu_ctx.ctx)) > 0
+    assert lib.rt_render(gpu_ctx.ctx, None, C.byref(pkg.make_params(64, 64)), pkg.fptr(out)) == -1
+    assert lib.rt_render(gpu_ctx.ctx, C.byref(cam), C.byref(pkg.make_params(64, 64)), None) == -1
+    assert lib.rt_upload_scene(gpu_ctx.ctx, None) == -1
+    assert lib.rt_create(99, C.byref(C.c_void_p())) == -1
+    # the context is still usable afterwards
+    gpu_ctx.render(cam, pkg.make_params(64, 64))
+
+
+def test_two_contexts_are_independent(pkg, oracle, scenes):
+    a, b = pkg.RenderContext(0), pkg.RenderContext(0)
+    a.upload_scene(scenes("teapot"))
+    b.upload_scene(scenes("model"))
+    cam = pkg.make_camera()
+    p = pkg.make_params(160, 90, frames=2)
+    ia, ib = a.render(cam, p), b.render(cam, p)
+    wa, _ = oracle.render(scenes("teapot"), cam, p)
+    wb, _ = oracle.render(scenes("model"), cam, p)
+    assert np.array_equal(bits(ia), bits(wa)) and np.array_equal(bits(ib), bits(wb))
+    a.close()
+    b.close()
