@@ -125,6 +125,21 @@ int rt_upload_scene(rt_context* ctx, const rt_scene* scene);
  * buffer, raytrace.glsl:33-35). */
 int rt_get_normals(rt_context* ctx, float* out_normals);
 
+/* GPU BVH build (no counterpart in the reference, whose builder is host code: bvh.cpp:136-173; this is the
+ * "per-frame rebuild" path for animated meshes).  Builds a binned-SAH BVH (16 bins, the reference's cost model
+ * bvh.cpp:24-56 and depth cap constants.h:26) over the given triangle soup ON THE DEVICE and makes it the
+ * context's scene, as rt_upload_scene would.  vertices: num_vertices x 3 floats, faces: num_faces x 3 indices
+ * (0-based), face_colours: num_faces x 4 floats, all host pointers.  Triangle ids reported by rt_primary_hits
+ * index the leaf-ordered arrays returned by rt_get_built_scene.  Synchronises. */
+int rt_build_scene_device(rt_context* ctx, const float* vertices, int32_t num_vertices, const uint32_t* faces,
+                          int32_t num_faces, const float* face_colours);
+/* Downloads the device-built scene in the layout of rt_scene (so that any other implementation of the path can
+ * render the very same tree): nodes num_nodes x 12, triv0/1/2 and colours num_tris x 4 in leaf order, tri_src
+ * = face index of each leaf-ordered triangle, build_ms = device time of the build.  Any pointer may be NULL;
+ * call once with only the two counts to size the arrays. */
+int rt_get_built_scene(rt_context* ctx, int32_t* num_nodes, int32_t* num_tris, float* nodes, float* triv0, float* triv1,
+                       float* triv2, float* colours, int32_t* tri_src, float* build_ms);
+
 /* ---- rendering --------------------------------------------------------------------- */
 /* One dispatch of the reference: raytrace(cameraPos, cameraRotation, renderMode, frameCount,
  * ...) (raytrace.h:10) with image unit 6 = d_prev_frame (read) and unit 5 = d_out_frame

@@ -113,6 +113,8 @@ HIP_SYMBOLS = [
     "rt_synchronize",
     "rt_upload_scene",
     "rt_get_normals",
+    "rt_build_scene_device",
+    "rt_get_built_scene",
     "rt_raytrace_frame",
     "rt_render_device",
     "rt_render",
@@ -174,6 +176,9 @@ def load_hip() -> C.CDLL:
         lib.rt_synchronize.argtypes = [vp]
         lib.rt_upload_scene.argtypes = [vp, C.POINTER(RtScene)]
         lib.rt_get_normals.argtypes = [vp, c_float_p]
+        lib.rt_build_scene_device.argtypes = [vp, c_float_p, C.c_int32, c_uint32_p, C.c_int32, c_float_p]
+        lib.rt_get_built_scene.argtypes = [vp, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                           c_int32_p, c_float_p]
         lib.rt_raytrace_frame.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, vp, vp]
         lib.rt_render_device.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), vp]
         lib.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), c_float_p]
@@ -331,6 +336,26 @@ class RenderContext:
         s = scene.as_rt_scene()
         self._check(self.lib.rt_upload_scene(self.ctx, C.byref(s)), "rt_upload_scene")
         self.num_tris = scene.num_tris
+
+    def build_scene_device(self, vertices: np.ndarray, faces: np.ndarray, face_colours: np.ndarray):
+        """GPU binned-SAH build; returns the built scene downloaded in the reference layout (a Scene) and the
+        device build time in milliseconds."""
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        col = np.ascontiguousarray(face_colours, dtype=np.float32).reshape(-1, 4)
+        assert col.shape[0] == f.shape[0]
+        self._check(self.lib.rt_build_scene_device(self.ctx, fptr(v), v.shape[0], f.ctypes.data_as(c_uint32_p), f.shape[0],
+                                                   fptr(col)), "rt_build_scene_device")
+        self.num_tris = f.shape[0]
+        n, t, ms = C.c_int32(), C.c_int32(), C.c_float()
+        self._check(self.lib.rt_get_built_scene(self.ctx, C.byref(n), C.byref(t), None, None, None, None, None, None, C.byref(ms)),
+                    "rt_get_built_scene")
+        nodes = np.empty((n.value, 12), dtype=np.float32)
+        v0, v1, v2, cc = (np.empty((t.value, 4), dtype=np.float32) for _ in range(4))
+        src = np.empty(t.value, dtype=np.int32)
+        self._check(self.lib.rt_get_built_scene(self.ctx, None, None, fptr(nodes), fptr(v0), fptr(v1), fptr(v2), fptr(cc),
+                                                src.ctypes.data_as(c_int32_p), None), "rt_get_built_scene")
+        return Scene(nodes, v0, v1, v2, cc, src, {"build_ms": ms.value}), ms.value
 
     def get_normals(self) -> np.ndarray:
         out = np.empty((self.num_tris, 4), dtype=np.float32)

@@ -29,6 +29,7 @@
 #include "rt_device.h"
 #include "rt_paths.h"
 #include "rt_paths2.h"
+#include "rt_build.h"
 
 #define RT_WF_BOUNCES 2       // bounces handled by wavefront kernels before the tail launch
 #define RT_TAIL_BLOCKS 1024   // grid of the tail kernel (grid-stride)
@@ -358,6 +359,12 @@ struct rt_context {
     float4* d_shade = nullptr;
     int num_tris = 0;
     int max_depth = 0;
+    // reference-layout copy of a scene built on the device (rt_build_scene_device), for rt_get_built_scene
+    float* d_ref_nodes = nullptr;
+    float4 *d_ref_v0 = nullptr, *d_ref_v1 = nullptr, *d_ref_v2 = nullptr, *d_ref_col = nullptr;
+    uint32_t* d_ref_src = nullptr;
+    int built_nodes = 0;
+    float last_build_ms = 0.0f;
 
     // per-resolution buffers
     size_t cap_slots = 0;  // queue capacity (padded pixel count)
@@ -421,6 +428,13 @@ static void free_scene(rt_context* c) {
     dfree(c->d_nodes);
     dfree(c->d_tris);
     dfree(c->d_shade);
+    dfree(c->d_ref_nodes);
+    dfree(c->d_ref_v0);
+    dfree(c->d_ref_v1);
+    dfree(c->d_ref_v2);
+    dfree(c->d_ref_col);
+    dfree(c->d_ref_src);
+    c->built_nodes = 0;
     c->has_scene = false;
 }
 
@@ -884,6 +898,164 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     c->has_scene = true;
     // a deeper tree may need a larger spill area: force re-allocation on the next render
     if (c->max_depth > RT_LDS_STACK && (size_t)(c->max_depth - RT_LDS_STACK + 1) > c->spill_entries) free_buffers(c);
+    return RT_OK;
+}
+
+// ---- GPU BVH build (rt_build.h) ---------------------------------------------------------------------------
+int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vertices, const uint32_t* faces,
+                          int32_t num_faces, const float* face_colours) {
+    if (!c) return RT_EINVAL;
+    if (!vertices || !faces || !face_colours) return fail(c, RT_EINVAL, "NULL argument");
+    if (num_vertices < 1 || num_faces < 1) return fail(c, RT_EINVAL, "need at least one vertex and one face");
+    if ((int64_t)num_faces > (int64_t)0x3ffffff0) return fail(c, RT_ELIMIT, "too many faces");
+    for (int64_t i = 0; i < (int64_t)num_faces * 3; i++)
+        if (faces[i] >= (uint32_t)num_vertices) return fail(c, RT_EINVAL, "face %lld references vertex %u of %d", (long long)(i / 3), faces[i], num_vertices);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    const int nf = num_faces, max_nodes = 2 * nf;
+    const size_t max_active = (size_t)nf / 2 + 2;
+    hipStream_t st = c->stream;
+
+    float* d_verts = nullptr;
+    uint32_t* d_faces = nullptr;
+    float4* d_fcol = nullptr;
+    uint32_t* d_root = nullptr;
+    BuildState s{};
+    std::vector<void*> temps;
+    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e == hipSuccess) temps.push_back(*p);
+        return e;
+    };
+    auto cleanup = [&]() {
+        for (void* p : temps) (void)hipFree(p);
+        temps.clear();
+    };
+#define BCHK(call)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            cleanup();                                                                          \
+            free_scene(c);                                                                      \
+            return fail(c, RT_EDEVICE, "%s: %s", #call, hipGetErrorString(e_));                 \
+        }                                                                                       \
+    } while (0)
+    BCHK(dalloc((void**)&d_verts, (size_t)num_vertices * 3 * sizeof(float)));
+    BCHK(dalloc((void**)&d_faces, (size_t)nf * 3 * sizeof(uint32_t)));
+    BCHK(dalloc((void**)&d_fcol, (size_t)nf * sizeof(float4)));
+    BCHK(dalloc((void**)&d_root, 12 * sizeof(uint32_t)));
+    BCHK(dalloc((void**)&s.tcen, (size_t)nf * sizeof(float4)));
+    BCHK(dalloc((void**)&s.tmin, (size_t)nf * sizeof(float4)));
+    BCHK(dalloc((void**)&s.tmax, (size_t)nf * sizeof(float4)));
+    for (int k = 0; k < 2; k++) {
+        BCHK(dalloc((void**)&s.order[k], (size_t)nf * sizeof(uint32_t)));
+        BCHK(dalloc((void**)&s.node_of[k], (size_t)nf * sizeof(int32_t)));
+        BCHK(dalloc((void**)&s.active[k], max_active * sizeof(int32_t)));
+    }
+    BCHK(dalloc((void**)&s.nmin, (size_t)max_nodes * sizeof(float4)));
+    BCHK(dalloc((void**)&s.nmax, (size_t)max_nodes * sizeof(float4)));
+    BCHK(dalloc((void**)&s.cmin, (size_t)max_nodes * sizeof(float4)));
+    BCHK(dalloc((void**)&s.cmax, (size_t)max_nodes * sizeof(float4)));
+    int32_t** nints[] = {&s.nstart, &s.ncount, &s.nchild, &s.ndepth, &s.nrec, &s.nslot, &s.nsplit, &s.cursors};
+    for (auto pp : nints) BCHK(dalloc((void**)pp, (size_t)max_nodes * sizeof(int32_t)));
+    BCHK(dalloc((void**)&s.bins, max_active * BB_NODE_WORDS * sizeof(uint32_t)));
+    BCHK(dalloc((void**)&s.counters, 8 * sizeof(int32_t)));
+
+    BCHK(hipMemcpyAsync(d_verts, vertices, (size_t)num_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, st));
+    BCHK(hipMemcpyAsync(d_faces, faces, (size_t)nf * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    BCHK(hipMemcpyAsync(d_fcol, face_colours, (size_t)nf * sizeof(float4), hipMemcpyHostToDevice, st));
+    const uint32_t root_init[12] = {BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF,
+                                    BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF};
+    BCHK(hipMemcpyAsync(d_root, root_init, sizeof root_init, hipMemcpyHostToDevice, st));
+    BCHK(hipStreamSynchronize(st));
+
+    hipEvent_t ev0, ev1;
+    BCHK(hipEventCreate(&ev0));
+    BCHK(hipEventCreate(&ev1));
+    BCHK(hipEventRecord(ev0, st));
+    const dim3 blk(BB_BLOCK), grid_t((nf + BB_BLOCK - 1) / BB_BLOCK);
+    hipLaunchKernelGGL(k_build_prep, grid_t, blk, 0, st, d_verts, d_faces, nf, s, d_root);
+    hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, st, s, d_root, nf);
+    int cur = 0, cur_list = 0, levels = 0;
+    int32_t h_counters[4] = {0, 0, 0, 0};
+    for (;;) {
+        BCHK(hipMemcpyAsync(h_counters, s.counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
+        BCHK(hipStreamSynchronize(st));
+        const int active = h_counters[2];
+        if (active <= 0 || levels > BB_MAX_DEPTH + 1) break;
+        const size_t words = (size_t)active * BB_NODE_WORDS;
+        hipLaunchKernelGGL(k_build_clear_bins, dim3((unsigned)((words + BB_BLOCK - 1) / BB_BLOCK)), blk, 0, st, s.bins, words);
+        BCHK(hipMemsetAsync(s.counters + 2, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_build_bin, grid_t, blk, 0, st, s, cur, nf);
+        hipLaunchKernelGGL(k_build_split, dim3((active + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, cur_list, active, max_nodes);
+        hipLaunchKernelGGL(k_build_partition, grid_t, blk, 0, st, s, cur, nf);
+        BCHK(hipGetLastError());
+        cur ^= 1;
+        cur_list ^= 1;
+        levels++;
+    }
+    const int num_nodes = h_counters[0], num_recs = h_counters[1], depth = h_counters[3];
+
+    // persistent outputs
+    BCHK(hipMalloc(&c->d_nodes, (size_t)(num_recs ? num_recs : 1) * 4 * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_tris, (size_t)nf * 4 * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_shade, (size_t)nf * 2 * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_ref_nodes, (size_t)num_nodes * 12 * sizeof(float)));
+    BCHK(hipMalloc(&c->d_ref_v0, (size_t)nf * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_ref_v1, (size_t)nf * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_ref_v2, (size_t)nf * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_ref_col, (size_t)nf * sizeof(float4)));
+    BCHK(hipMalloc(&c->d_ref_src, (size_t)nf * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_build_emit_nodes, dim3((num_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, num_nodes, c->d_ref_nodes, c->d_nodes);
+    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, s, cur, nf, d_verts, d_faces, d_fcol, c->d_tris, c->d_ref_v0, c->d_ref_v1,
+                       c->d_ref_v2, c->d_ref_col);
+    hipLaunchKernelGGL(k_normals, dim3((nf + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->d_ref_v0, c->d_ref_v1, c->d_ref_v2,
+                       c->d_ref_col, c->d_shade, nf);
+    BCHK(hipMemcpyAsync(c->d_ref_src, s.order[cur], (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    BCHK(hipEventRecord(ev1, st));
+    float4 rlo, rhi;
+    BCHK(hipMemcpyAsync(&rlo, s.nmin, sizeof rlo, hipMemcpyDeviceToHost, st));
+    BCHK(hipMemcpyAsync(&rhi, s.nmax, sizeof rhi, hipMemcpyDeviceToHost, st));
+    BCHK(hipGetLastError());
+    BCHK(hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&c->last_build_ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    cleanup();
+#undef BCHK
+
+    c->sc.nodes = c->d_nodes;
+    c->sc.tris = c->d_tris;
+    c->sc.shade = c->d_shade;
+    c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
+    c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
+    c->sc.root_ref = num_nodes == 1 ? ~0 : 0;  // a single leaf starts at triangle 0; otherwise the root owns record 0
+    c->sc.num_tris = nf;
+    c->num_tris = nf;
+    c->max_depth = depth;
+    c->cache_recs = num_recs < RT_BFS_PREFIX ? num_recs : RT_BFS_PREFIX;  // records are numbered level by level
+    c->built_nodes = num_nodes;
+    c->has_scene = true;
+    if (c->max_depth > RT_LDS_STACK && (size_t)(c->max_depth - RT_LDS_STACK + 1) > c->spill_entries) free_buffers(c);
+    return RT_OK;
+}
+
+int rt_get_built_scene(rt_context* c, int32_t* num_nodes, int32_t* num_tris, float* nodes, float* triv0, float* triv1,
+                       float* triv2, float* colours, int32_t* tri_src, float* build_ms) {
+    if (!c) return RT_EINVAL;
+    if (!c->has_scene || !c->d_ref_nodes) return fail(c, RT_ENOSCENE, "the current scene was not built on the device");
+    if (num_nodes) *num_nodes = c->built_nodes;
+    if (num_tris) *num_tris = c->num_tris;
+    if (build_ms) *build_ms = c->last_build_ms;
+    const size_t T = (size_t)c->num_tris;
+    if (nodes) HIPCHK(c, hipMemcpyAsync(nodes, c->d_ref_nodes, (size_t)c->built_nodes * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (triv0) HIPCHK(c, hipMemcpyAsync(triv0, c->d_ref_v0, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (triv1) HIPCHK(c, hipMemcpyAsync(triv1, c->d_ref_v1, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (triv2) HIPCHK(c, hipMemcpyAsync(triv2, c->d_ref_v2, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (colours) HIPCHK(c, hipMemcpyAsync(colours, c->d_ref_col, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (tri_src) HIPCHK(c, hipMemcpyAsync(tri_src, c->d_ref_src, T * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

@@ -1,0 +1,395 @@
+// GPU BVH builder: level-synchronous, top-down, binned SAH (16 bins x 3 axes), one pass over the triangles per
+// kernel and level.  It is a NEW algorithm, not the reference's ternary-search builder (bvh.cpp:54-134), so it
+// yields a different tree and triangle order; what it keeps from the reference is the cost model
+// (bvh.cpp:24-56: SA = 6(dx*dy + dx*dz + dy*dz), split cost 1 + 50 nL SA_L + 50 nR SA_R against 50 n SA for a
+// leaf), the depth cap MAX_BVH_DEPTH = 32 and the node semantics the traversal expects (leaf = inclusive triangle
+// range in leaf order).  The result can be downloaded in the reference's buffer layout (rt_get_built_scene) so
+// that the CPU oracle renders the very same tree.
+//
+// Per level, over the triangle array in its current order (every node owns a contiguous segment):
+//   k_bin        each triangle of an active node adds its box to the node's (axis, bin) accumulators -- count and
+//                bounds, as order-independent integer atomics (min/max on an order-preserving key), privatised in
+//                LDS when a whole workgroup sits in one node (the top levels);
+//   k_split      one lane per active node sweeps the 3 x 15 candidate planes, decides split or leaf, allocates the
+//                two children (breadth-first ids) and the node's record id;
+//   k_partition  each triangle of a split node moves to its child's segment; destinations come from per-child
+//                cursors, aggregated per wave (ballot + mbcnt, one atomic per wave and child).
+// The bins, bounds and split decisions are deterministic; the order of triangles INSIDE a leaf depends on the
+// atomics' arrival order.
+#ifndef RT_BUILD_H
+#define RT_BUILD_H
+
+#include "rt_device.h"
+
+#define BB_BINS 16
+#define BB_WORDS 7                               // count + 6 bounds keys per bin
+#define BB_NODE_WORDS (3 * BB_BINS * BB_WORDS)   // 336 words of accumulators per active node
+#define BB_MAX_DEPTH 32                          // MAX_BVH_DEPTH, constants.h:26
+#define BB_BLOCK 256
+
+// order-preserving map float -> uint32 so that integer atomicMin/Max act as float min/max
+__device__ __forceinline__ uint32_t bb_key(float f) {
+    uint32_t u = rt_f2u(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float bb_unkey(uint32_t k) { return rt_u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+#define BB_KEY_POS_INF 0xff800000u   // bb_key(+inf)
+#define BB_KEY_NEG_INF 0x007fffffu   // bb_key(-inf)
+
+struct BuildState {
+    // per triangle (original face index): centroid and box
+    float4* tcen;
+    float4* tmin;
+    float4* tmax;
+    // per position: triangle at that position and the node owning it (ping-pong)
+    uint32_t* order[2];
+    int32_t* node_of[2];
+    // per node
+    float4* nmin;        // bounds
+    float4* nmax;
+    float4* cmin;        // centroid bounds
+    float4* cmax;
+    int32_t* nstart;
+    int32_t* ncount;
+    int32_t* nchild;     // first child (second = +1) or -1 for a leaf
+    int32_t* ndepth;
+    int32_t* nrec;       // inner-node record id or -1
+    int32_t* nslot;      // slot in this level's active list or -1
+    int32_t* nsplit;     // axis | bin << 2 of the split chosen this level, or -1
+    // per level
+    int32_t* active[2];  // active node lists (ping-pong)
+    uint32_t* bins;      // active_count x BB_NODE_WORDS
+    int32_t* cursors;    // per node: next free position of its segment during partition
+    int32_t* counters;   // [0] nodes allocated, [1] records allocated, [2] next level's active count, [3] max depth
+};
+
+__device__ __forceinline__ int bb_bin(float c, float lo, float hi) {
+    float ext = hi - lo;
+    if (!(ext > 0.0f)) return 0;
+    int b = (int)((c - lo) * ((float)BB_BINS / ext));
+    return b < 0 ? 0 : (b > BB_BINS - 1 ? BB_BINS - 1 : b);
+}
+
+// centroid, box per triangle; root bounds by atomics
+__global__ __launch_bounds__(BB_BLOCK) void k_build_prep(const float* verts, const uint32_t* faces, int nf, BuildState s,
+                                                         uint32_t* root_keys /*12: nmin nmax cmin cmax*/) {
+    int i = blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (i >= nf) return;
+    uint32_t ia = faces[3 * i], ib = faces[3 * i + 1], ic = faces[3 * i + 2];
+    rt_vec3 a = rt_v3(verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]);
+    rt_vec3 b = rt_v3(verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]);
+    rt_vec3 c = rt_v3(verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]);
+    rt_vec3 lo = rt_v3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+    rt_vec3 hi = rt_v3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+    rt_vec3 ce = rt_v3(((a.x + b.x) + c.x) / 3.0f, ((a.y + b.y) + c.y) / 3.0f, ((a.z + b.z) + c.z) / 3.0f);  // bvh.cpp:156
+    s.tcen[i] = make_float4(ce.x, ce.y, ce.z, 0.0f);
+    s.tmin[i] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    s.tmax[i] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+    s.order[0][i] = (uint32_t)i;
+    s.node_of[0][i] = 0;
+    const float v[12] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, ce.x, ce.y, ce.z, ce.x, ce.y, ce.z};
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        bool is_min = k < 3 || (k >= 6 && k < 9);
+        if (is_min)
+            atomicMin(&root_keys[k], bb_key(v[k]));
+        else
+            atomicMax(&root_keys[k], bb_key(v[k]));
+    }
+}
+
+__global__ void k_build_root(BuildState s, const uint32_t* root_keys, int nf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    s.nmin[0] = make_float4(bb_unkey(root_keys[0]), bb_unkey(root_keys[1]), bb_unkey(root_keys[2]), 0.0f);
+    s.nmax[0] = make_float4(bb_unkey(root_keys[3]), bb_unkey(root_keys[4]), bb_unkey(root_keys[5]), 0.0f);
+    s.cmin[0] = make_float4(bb_unkey(root_keys[6]), bb_unkey(root_keys[7]), bb_unkey(root_keys[8]), 0.0f);
+    s.cmax[0] = make_float4(bb_unkey(root_keys[9]), bb_unkey(root_keys[10]), bb_unkey(root_keys[11]), 0.0f);
+    s.nstart[0] = 0;
+    s.ncount[0] = nf;
+    s.nchild[0] = -1;
+    s.ndepth[0] = 0;
+    s.nrec[0] = -1;
+    s.nsplit[0] = -1;
+    bool act = nf >= 2;
+    s.nslot[0] = act ? 0 : -1;
+    s.active[0][0] = 0;
+    s.counters[0] = 1;
+    s.counters[1] = 0;
+    s.counters[2] = act ? 1 : 0;
+    s.counters[3] = 0;
+}
+
+__global__ __launch_bounds__(BB_BLOCK) void k_build_clear_bins(uint32_t* bins, size_t words) {
+    size_t i = (size_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (i >= words) return;
+    uint32_t w = (uint32_t)(i % BB_WORDS);
+    bins[i] = w == 0 ? 0u : (w <= 3 ? BB_KEY_POS_INF : BB_KEY_NEG_INF);
+}
+
+__device__ __forceinline__ void bb_accumulate(uint32_t* b, float4 lo, float4 hi) {
+    atomicAdd(&b[0], 1u);
+    atomicMin(&b[1], bb_key(lo.x));
+    atomicMin(&b[2], bb_key(lo.y));
+    atomicMin(&b[3], bb_key(lo.z));
+    atomicMax(&b[4], bb_key(hi.x));
+    atomicMax(&b[5], bb_key(hi.y));
+    atomicMax(&b[6], bb_key(hi.z));
+}
+
+__global__ __launch_bounds__(BB_BLOCK) void k_build_bin(BuildState s, int cur, int n) {
+    __shared__ uint32_t l_bins[BB_NODE_WORDS];
+    __shared__ int l_node, l_uniform;
+    int i = blockIdx.x * BB_BLOCK + threadIdx.x;
+    int node = i < n ? s.node_of[cur][i] : -2;
+    int slot = node >= 0 ? s.nslot[node] : -1;
+    // is the whole workgroup inside one active node?
+    if (threadIdx.x == 0) {
+        l_node = node;
+        l_uniform = 1;
+    }
+    __syncthreads();
+    if (node != l_node || slot < 0) l_uniform = 0;
+    for (int k = threadIdx.x; k < BB_NODE_WORDS; k += BB_BLOCK) {
+        uint32_t w = (uint32_t)(k % BB_WORDS);
+        l_bins[k] = w == 0 ? 0u : (w <= 3 ? BB_KEY_POS_INF : BB_KEY_NEG_INF);
+    }
+    __syncthreads();
+    const bool uniform = l_uniform != 0;
+    if (slot >= 0) {
+        uint32_t t = s.order[cur][i];
+        float4 ce = s.tcen[t], lo = s.tmin[t], hi = s.tmax[t];
+        float4 c0 = s.cmin[node], c1 = s.cmax[node];
+        int b[3] = {bb_bin(ce.x, c0.x, c1.x), bb_bin(ce.y, c0.y, c1.y), bb_bin(ce.z, c0.z, c1.z)};
+        uint32_t* base = uniform ? l_bins : s.bins + (size_t)slot * BB_NODE_WORDS;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) bb_accumulate(base + (ax * BB_BINS + b[ax]) * BB_WORDS, lo, hi);
+    }
+    __syncthreads();
+    if (uniform) {
+        uint32_t* g = s.bins + (size_t)s.nslot[l_node] * BB_NODE_WORDS;
+        for (int k = threadIdx.x; k < BB_NODE_WORDS; k += BB_BLOCK) {
+            uint32_t w = (uint32_t)(k % BB_WORDS), v = l_bins[k];
+            if (w == 0) {
+                if (v) atomicAdd(&g[k], v);
+            } else if (w <= 3) {
+                if (v != BB_KEY_POS_INF) atomicMin(&g[k], v);
+            } else {
+                if (v != BB_KEY_NEG_INF) atomicMax(&g[k], v);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float bb_area6(const float* lo, const float* hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 6.0f * ((dx * dy + dx * dz) + dy * dz);
+}
+
+// One lane per active node: choose the split, create the children.
+__global__ __launch_bounds__(BB_BLOCK) void k_build_split(BuildState s, int cur_list, int num_active, int max_nodes) {
+    int a = blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (a >= num_active) return;
+    const int node = s.active[cur_list][a];
+    const uint32_t* bins = s.bins + (size_t)a * BB_NODE_WORDS;
+    const int n = s.ncount[node], depth = s.ndepth[node];
+    const float4 nlo4 = s.nmin[node], nhi4 = s.nmax[node];
+    const float nlo[3] = {nlo4.x, nlo4.y, nlo4.z}, nhi[3] = {nhi4.x, nhi4.y, nhi4.z};
+    float best_cost = (50.0f * (float)n) * bb_area6(nlo, nhi);  // leaf cost
+    int best_axis = -1, best_bin = 0, best_nl = 0;
+    float bl_lo[3], bl_hi[3], br_lo[3], br_hi[3];
+    if (depth < BB_MAX_DEPTH) {
+        for (int ax = 0; ax < 3; ax++) {
+            const uint32_t* bb = bins + ax * BB_BINS * BB_WORDS;
+            // suffix unions from the right
+            float rlo[BB_BINS][3], rhi[BB_BINS][3];
+            int rcnt[BB_BINS];
+            float lo[3] = {RT_INF, RT_INF, RT_INF}, hi[3] = {-RT_INF, -RT_INF, -RT_INF};
+            int cnt = 0;
+            for (int b = BB_BINS - 1; b >= 1; b--) {
+                const uint32_t* w = bb + b * BB_WORDS;
+                cnt += (int)w[0];
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = fminf(lo[k], bb_unkey(w[1 + k]));
+                    hi[k] = fmaxf(hi[k], bb_unkey(w[4 + k]));
+                    rlo[b][k] = lo[k];
+                    rhi[b][k] = hi[k];
+                }
+                rcnt[b] = cnt;
+            }
+            float llo[3] = {RT_INF, RT_INF, RT_INF}, lhi[3] = {-RT_INF, -RT_INF, -RT_INF};
+            int lcnt = 0;
+            for (int sp = 0; sp < BB_BINS - 1; sp++) {  // left = bins [0..sp], right = bins [sp+1..15]
+                const uint32_t* w = bb + sp * BB_WORDS;
+                lcnt += (int)w[0];
+                for (int k = 0; k < 3; k++) {
+                    llo[k] = fminf(llo[k], bb_unkey(w[1 + k]));
+                    lhi[k] = fmaxf(lhi[k], bb_unkey(w[4 + k]));
+                }
+                int rc = rcnt[sp + 1];
+                if (lcnt == 0 || rc == 0) continue;
+                float cost = (1.0f + (50.0f * (float)lcnt) * bb_area6(llo, lhi)) + (50.0f * (float)rc) * bb_area6(rlo[sp + 1], rhi[sp + 1]);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = ax;
+                    best_bin = sp;
+                    best_nl = lcnt;
+                    for (int k = 0; k < 3; k++) {
+                        bl_lo[k] = llo[k];
+                        bl_hi[k] = lhi[k];
+                        br_lo[k] = rlo[sp + 1][k];
+                        br_hi[k] = rhi[sp + 1][k];
+                    }
+                }
+            }
+        }
+    }
+    s.nslot[node] = -1;
+    if (best_axis < 0) {  // leaf
+        s.nsplit[node] = -1;
+        return;
+    }
+    int c0 = atomicAdd(&s.counters[0], 2);
+    if (c0 + 2 > max_nodes) {  // cannot happen with max_nodes = 2*nf, keep the tree valid anyway
+        s.nsplit[node] = -1;
+        return;
+    }
+    s.nrec[node] = atomicAdd(&s.counters[1], 1);
+    s.nchild[node] = c0;
+    s.nsplit[node] = best_axis | (best_bin << 2);
+    atomicMax(&s.counters[3], depth + 1);
+    const int start = s.nstart[node];
+    const float4 c0lo = s.cmin[node], c0hi = s.cmax[node];
+    const float clo[3] = {c0lo.x, c0lo.y, c0lo.z}, chi[3] = {c0hi.x, c0hi.y, c0hi.z};
+    // plane between bin best_bin and best_bin+1 on the split axis, for the children's centroid bounds
+    float plane = clo[best_axis] + (chi[best_axis] - clo[best_axis]) * ((float)(best_bin + 1) / (float)BB_BINS);
+    for (int side = 0; side < 2; side++) {
+        int c = c0 + side;
+        const float* lo = side ? br_lo : bl_lo;
+        const float* hi = side ? br_hi : bl_hi;
+        int cnt = side ? n - best_nl : best_nl;
+        float ccl[3] = {clo[0], clo[1], clo[2]}, cch[3] = {chi[0], chi[1], chi[2]};
+        if (side)
+            ccl[best_axis] = plane;
+        else
+            cch[best_axis] = plane;
+        // centroid bounds may not exceed the child's own box
+        for (int k = 0; k < 3; k++) {
+            ccl[k] = fmaxf(ccl[k], lo[k]);
+            cch[k] = fminf(cch[k], hi[k]);
+        }
+        s.nmin[c] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        s.nmax[c] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        s.cmin[c] = make_float4(ccl[0], ccl[1], ccl[2], 0.0f);
+        s.cmax[c] = make_float4(cch[0], cch[1], cch[2], 0.0f);
+        s.nstart[c] = side ? start + best_nl : start;
+        s.ncount[c] = cnt;
+        s.nchild[c] = -1;
+        s.ndepth[c] = depth + 1;
+        s.nrec[c] = -1;
+        s.nsplit[c] = -1;
+        s.cursors[c] = side ? start + best_nl : start;
+        bool act = cnt >= 2 && depth + 1 < BB_MAX_DEPTH;
+        int slot = -1;
+        if (act) {
+            slot = atomicAdd(&s.counters[2], 1);
+            s.active[cur_list ^ 1][slot] = c;
+        }
+        s.nslot[c] = slot;
+    }
+}
+
+// Moves every triangle of a node split this level into its child's segment.
+__global__ __launch_bounds__(BB_BLOCK) void k_build_partition(BuildState s, int cur, int n) {
+    int i = blockIdx.x * BB_BLOCK + threadIdx.x;
+    bool in = i < n;
+    int node = in ? s.node_of[cur][i] : -1;
+    uint32_t t = in ? s.order[cur][i] : 0u;
+    int sp = node >= 0 ? s.nsplit[node] : -1;
+    int child = -1;
+    if (sp >= 0) {
+        int ax = sp & 3, bin = sp >> 2;
+        float4 ce = s.tcen[t], c0 = s.cmin[node], c1 = s.cmax[node];
+        float c = ax == 0 ? ce.x : (ax == 1 ? ce.y : ce.z);
+        float lo = ax == 0 ? c0.x : (ax == 1 ? c0.y : c0.z), hi = ax == 0 ? c1.x : (ax == 1 ? c1.y : c1.z);
+        child = s.nchild[node] + (bb_bin(c, lo, hi) > bin ? 1 : 0);
+    }
+    int dest = i;
+    // wave-aggregated cursor allocation: one atomic per distinct child present in the wave
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(child >= 0);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int c = __shfl(child, leader, 64);
+        unsigned long long same = __builtin_amdgcn_ballot_w64(child == c);
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&s.cursors[c], (int)__builtin_popcountll(same));
+        base = __shfl(base, leader, 64);
+        if (child == c) dest = base + (int)rank;
+        todo &= ~same;
+    }
+    if (in) {
+        s.order[cur ^ 1][dest] = t;
+        s.node_of[cur ^ 1][dest] = child >= 0 ? child : node;
+    }
+}
+
+// ---- emission ---------------------------------------------------------------------------------------------------
+// reference-format node rows (for download) and the 64-byte inner-node records of the render kernels
+__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_nodes(BuildState s, int num_nodes, float* ref_nodes, float4* recs) {
+    int i = blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (i >= num_nodes) return;
+    float4 lo = s.nmin[i], hi = s.nmax[i];
+    int c0 = s.nchild[i];
+    float* r = ref_nodes + (size_t)12 * i;
+    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = 0.0f;
+    r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = 0.0f;
+    r[11] = 0.0f;
+    if (c0 < 0) {
+        r[8] = 1.0f;
+        r[9] = (float)s.nstart[i];
+        r[10] = (float)(s.nstart[i] + s.ncount[i] - 1);
+        return;
+    }
+    r[8] = 0.0f;
+    r[9] = (float)c0;
+    r[10] = (float)(c0 + 1);
+    int ref[2];
+    float4 blo[2], bhi[2];
+    for (int k = 0; k < 2; k++) {
+        int c = c0 + k;
+        blo[k] = s.nmin[c];
+        bhi[k] = s.nmax[c];
+        ref[k] = s.nchild[c] >= 0 ? s.nrec[c] : (s.ncount[c] > 0 ? ~s.nstart[c] : RT_REF_EMPTY);
+    }
+    float4* q = recs + (size_t)s.nrec[i] * 4;
+    q[0] = make_float4(blo[0].x, blo[0].y, blo[0].z, bhi[0].x);
+    q[1] = make_float4(bhi[0].y, bhi[0].z, blo[1].x, blo[1].y);
+    q[2] = make_float4(blo[1].z, bhi[1].x, bhi[1].y, bhi[1].z);
+    q[3] = make_float4(rt_u2f((uint32_t)ref[0]), rt_u2f((uint32_t)ref[1]), 0.0f, 0.0f);
+}
+
+// triangle records, the reference's vertex arrays in leaf order, colours gathered by face
+__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int cur, int n, const float* verts,
+                                                              const uint32_t* faces, const float4* face_colours, float4* tris,
+                                                              float4* v0, float4* v1, float4* v2, float4* colours) {
+    int k = blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    uint32_t t = s.order[cur][k];
+    int node = s.node_of[cur][k];
+    uint32_t ia = faces[3 * t], ib = faces[3 * t + 1], ic = faces[3 * t + 2];
+    float4 a = make_float4(verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2], 0.0f);
+    float4 b = make_float4(verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2], 0.0f);
+    float4 c = make_float4(verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2], 0.0f);
+    v0[k] = a;
+    v1[k] = b;
+    v2[k] = c;
+    colours[k] = face_colours[t];
+    bool last = k == s.nstart[node] + s.ncount[node] - 1;
+    float4* q = tris + (size_t)k * 4;
+    q[0] = make_float4(a.x, a.y, a.z, rt_u2f(last ? 1u : 0u));
+    q[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, rt_u2f((uint32_t)k));
+    q[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0f);
+    q[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+#endif  // RT_BUILD_H
