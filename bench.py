@@ -67,6 +67,9 @@ def main() -> int:
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true", help="non-default: refresh invDir after bounces")
+    ap.add_argument("--partition", default="samples", choices=["samples", "tiles"],
+                    help="N > 1: 'samples' = each GPU renders its own frames (weak scaling, the default); 'tiles' = every "
+                         "GPU renders its horizontal band of every frame (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -112,7 +115,8 @@ def main() -> int:
     ctx.set_stream(stream.cuda_stream)
 
     # N = 1 accumulates with the reference's running mean; N > 1 needs plain sums for the reduce
-    base_flags = pkg.RT_FLAG_SUM if world > 1 else 0
+    tiles = args.partition == "tiles" and world > 1
+    base_flags = pkg.RT_FLAG_SUM if (world > 1 and not tiles) else 0
     if args.fix_invdir:
         base_flags |= pkg.RT_FLAG_FIX_INVDIR
     if args.pipeline == "megakernel":
@@ -124,8 +128,12 @@ def main() -> int:
     def render_steps(first_step: int, nsteps: int, flags: int, target, bounces: int = 100):
         """nsteps steps of this rank (frameCount (first_step+k)*world + rank) in ONE call of the boundary:
         the library is free to render the frames of a call concurrently."""
-        base, stride, n = partition.rank_frames(rank, world, first_step, nsteps)
-        p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=base, frames=n, frame_stride=stride, flags=flags)
+        if tiles:  # every rank renders the same frames, restricted to its band; bands are disjoint, so the
+            # closing sum-reduce of the (elsewhere zero) buffers is the gather
+            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=first_step, frames=nsteps, flags=flags, band=(rank, world))
+        else:
+            base, stride, n = partition.rank_frames(rank, world, first_step, nsteps)
+            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=base, frames=n, frame_stride=stride, flags=flags)
         ctx.render_device(cam, p, target.data_ptr())
 
     def barrier():
@@ -148,7 +156,7 @@ def main() -> int:
     render_steps(0, args.steps, base_flags, accum)
     if dist is not None:
         dist.reduce(accum, dst=0)
-    if rank == 0 and world > 1:
+    if rank == 0 and world > 1 and not tiles:
         accum.mul_(1.0 / float(args.steps * world))  # sum -> mean image
     barrier()
     elapsed = time.perf_counter() - t0
@@ -175,7 +183,7 @@ def main() -> int:
     else:
         counters_all = counters
     total_rays = float(counters_all[2])
-    frames_total = args.steps * world
+    frames_total = args.steps if tiles else args.steps * world
 
     # ---- untimed: per-kernel durations with HIP events on the launch stream ------------------------
     ctx.set_profiling(True)
@@ -218,7 +226,7 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if tiles else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -228,7 +236,7 @@ def main() -> int:
                             f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}",
                 "pipeline": args.pipeline,
                 "frames_total": frames_total,
-                "parallelism": f"sample-partition x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"tile-partition x{world}" if tiles else f"sample-partition x{world}") if world > 1 else "single GPU",
             },
             "rays_per_frame": round(total_rays / frames_total, 1),
             "work_per_ray": {

@@ -92,7 +92,11 @@ typedef struct rt_params {
     uint32_t frames;          /* number of frames (= spp at rays_per_pixel 1) */
     uint32_t frame_stride;    /* frameCount step between frames; 0 or 1 = consecutive */
     uint32_t flags;           /* RT_FLAG_* */
-    uint32_t reserved;
+    uint32_t band;            /* 0 = whole image; (index << 16) | count = render only horizontal band `index` of
+                                 `count` (image-tile partition across GPUs).  Bands are runs of 8-pixel tile rows:
+                                 band i covers tile rows [i*R/count, (i+1)*R/count), R = ceil(height/8); pixels
+                                 outside the band are neither read nor written; seeds use global pixel indices, so
+                                 the union of the bands is bit-identical to the whole image.  Default pipeline only. */
 } rt_params;
 
 typedef struct rt_context rt_context;

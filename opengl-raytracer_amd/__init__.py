@@ -88,7 +88,7 @@ class RtParams(C.Structure):
         ("frames", C.c_uint32),
         ("frame_stride", C.c_uint32),
         ("flags", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("band", C.c_uint32),
     ]
 
 
@@ -297,8 +297,10 @@ def make_camera(pos=(0.0, 0.0, -2.0), pitch=0.0, yaw=0.0, fov_deg=90.0, viewport
 
 
 def make_params(width=1920, height=1080, rays_per_pixel=1, ray_bounces=100, render_mode=1, frame_base=0, frames=1,
-                frame_stride=1, flags=0) -> RtParams:
-    return RtParams(width, height, rays_per_pixel, ray_bounces, render_mode, frame_base, frames, frame_stride, flags, 0)
+                frame_stride=1, flags=0, band=None) -> RtParams:
+    """band = (index, count) restricts the render to one horizontal band of the image (tile partition)."""
+    b = 0 if band is None else ((int(band[0]) << 16) | int(band[1]))
+    return RtParams(width, height, rays_per_pixel, ray_bounces, render_mode, frame_base, frames, frame_stride, flags, b)
 
 
 class RenderContext:

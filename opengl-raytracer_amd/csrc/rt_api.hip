@@ -515,6 +515,13 @@ static int check_render_args(rt_context* c, const rt_camera* cam, const rt_param
     if (p->rays_per_pixel == 0) return fail(c, RT_EINVAL, "rays_per_pixel must be at least 1");
     if (p->render_mode < RT_MODE_RENDER || p->render_mode > RT_MODE_REFLECTIONS)
         return fail(c, RT_EINVAL, "render_mode must be 1..4");
+    if (p->band) {
+        const uint32_t idx = p->band >> 16, cnt = p->band & 0xffffu;
+        if (cnt == 0 || idx >= cnt) return fail(c, RT_EINVAL, "band index %u out of range for %u bands", idx, cnt);
+        if ((p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) || p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 ||
+            p->ray_bounces == 0)
+            return fail(c, RT_EINVAL, "bands are supported by the default pipeline only (render mode 1, rays_per_pixel 1)");
+    }
     return RT_OK;
 }
 
@@ -555,6 +562,22 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     return RT_OK;
 }
 
+// Tile rows [ty0, ty1) and pixel range of the band selected by params->band (whole image for 0).
+static void band_rows(const rt_params* p, int* ty0, int* ty1, uint32_t* first_pixel, uint32_t* num_pixels) {
+    const int R = (p->height + 7) / 8;
+    int t0 = 0, t1 = R;
+    if (p->band) {
+        const int idx = (int)(p->band >> 16), cnt = (int)(p->band & 0xffffu);
+        t0 = (int)((int64_t)idx * R / cnt);
+        t1 = (int)((int64_t)(idx + 1) * R / cnt);
+    }
+    const int r0 = t0 * 8 < p->height ? t0 * 8 : p->height, r1 = t1 * 8 < p->height ? t1 * 8 : p->height;
+    *ty0 = t0;
+    *ty1 = t1;
+    *first_pixel = (uint32_t)r0 * (uint32_t)p->width;
+    *num_pixels = (uint32_t)(r1 - r0) * (uint32_t)p->width;
+}
+
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
 // them, in order, into out (reading prev).
 static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
@@ -570,8 +593,12 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     a.frame_stride = stride;
     a.num_frames = nframes;
     a.bounces = p->ray_bounces;
+    int ty0, ty1;
+    uint32_t first_pixel, num_pixels;
+    band_rows(p, &ty0, &ty1, &first_pixel, &num_pixels);
     a.tiles_x = (p->width + 7) / 8;
-    a.tiles_per_frame = a.tiles_x * ((p->height + 7) / 8);
+    a.tile_y0 = ty0;
+    a.tiles_per_frame = a.tiles_x * (ty1 - ty0);
     a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
     a.pixels = (uint32_t)pixels;
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
@@ -597,9 +624,10 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
         uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, c->stream,
-                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, frame_base, stride, sum ? 1u : 0u,
-                           read_prev, prev, out);
+        if (num_pixels)
+            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((num_pixels + 255) / 256)), dim3(256), 0, c->stream,
+                               (const float4*)c->d_samples, nframes, (uint32_t)pixels, first_pixel, num_pixels, frame_base, stride,
+                               sum ? 1u : 0u, read_prev, prev, out);
     }
     HIPCHK(c, hipGetLastError());
     return RT_OK;
@@ -657,8 +685,8 @@ static int launch_paths2_batch(rt_context* c, const DCamera& dc, const rt_params
         LaunchTimer lt(c, RT_K_ACCUMULATE);
         uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, c->stream,
-                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, frame_base, stride, sum ? 1u : 0u,
-                           read_prev, prev, out);
+                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, 0u, (uint32_t)pixels, frame_base, stride,
+                           sum ? 1u : 0u, read_prev, prev, out);
     }
     HIPCHK(c, hipGetLastError());
     return RT_OK;
@@ -1085,7 +1113,7 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
     if (!mega && !wavefront)
-        return c->use_paths2 ? launch_paths2_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame)
+        return (c->use_paths2 && !p->band) ? launch_paths2_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame)
                              : launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame);
     if ((rc = ensure_buffers(c, p->width, p->height)) != RT_OK) return rc;
 
@@ -1156,8 +1184,13 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     if (rc != RT_OK) return rc;
     if (!d_accum) return fail(c, RT_EINVAL, "d_accum is NULL");
     uint32_t stride = p->frame_stride ? p->frame_stride : 1u;
-    if ((p->flags & RT_FLAG_SUM) && p->frame_base == 0)
-        HIPCHK(c, hipMemsetAsync(d_accum, 0, (size_t)p->width * p->height * 4 * sizeof(float), c->stream));
+    if ((p->flags & RT_FLAG_SUM) && p->frame_base == 0) {
+        int ty0, ty1;
+        uint32_t first_pixel, num_pixels;
+        band_rows(p, &ty0, &ty1, &first_pixel, &num_pixels);  // only the band that will be rendered is cleared
+        if (num_pixels)
+            HIPCHK(c, hipMemsetAsync(d_accum + (size_t)first_pixel * 4, 0, (size_t)num_pixels * 4 * sizeof(float), c->stream));
+    }
     const bool per_frame = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) != 0 ||
                            p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 || p->ray_bounces == 0;
     if (per_frame) {
@@ -1172,7 +1205,7 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     DCamera dc = make_dcamera(cam, p->width, p->height);
     for (uint32_t f = 0; f < p->frames; f += PT_MAX_BATCH) {
         uint32_t n = p->frames - f < PT_MAX_BATCH ? p->frames - f : PT_MAX_BATCH;
-        rc = c->use_paths2 ? launch_paths2_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum)
+        rc = (c->use_paths2 && !p->band) ? launch_paths2_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum)
                            : launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum);
         if (rc != RT_OK) return rc;
     }
@@ -1191,13 +1224,22 @@ int rt_render(rt_context* c, const rt_camera* cam, const rt_params* p, float* ou
         HIPCHK(c, hipMalloc(&c->d_frame, pixels * sizeof(float4)));
         c->frame_pixels = pixels;
     }
-    if (p->frame_base != 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_frame, out_rgba, pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    else
-        HIPCHK(c, hipMemsetAsync(c->d_frame, 0, pixels * sizeof(float4), c->stream));
+    // only the band being rendered travels; the rest of the caller's buffer is left alone
+    int ty0, ty1;
+    uint32_t first_pixel, num_pixels;
+    band_rows(p, &ty0, &ty1, &first_pixel, &num_pixels);
+    float4* d_band = c->d_frame + first_pixel;
+    float* h_band = out_rgba + (size_t)first_pixel * 4;
+    if (num_pixels) {
+        if (p->frame_base != 0)
+            HIPCHK(c, hipMemcpyAsync(d_band, h_band, (size_t)num_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        else
+            HIPCHK(c, hipMemsetAsync(d_band, 0, (size_t)num_pixels * sizeof(float4), c->stream));
+    }
     rc = rt_render_device(c, cam, p, (float*)c->d_frame);
     if (rc != RT_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(out_rgba, c->d_frame, pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (num_pixels)
+        HIPCHK(c, hipMemcpyAsync(h_band, d_band, (size_t)num_pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -45,7 +45,8 @@ enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
 struct PathsArgs {
     uint32_t frame_base, frame_stride, num_frames;
     uint32_t bounces;
-    int tiles_x, tiles_per_frame;   // 8x8 pixel tiles
+    int tiles_x, tiles_per_frame;   // 8x8 pixel tiles (of the band being rendered)
+    int tile_y0;                    // first tile row of the band
     uint32_t total_tiles;           // num_frames * tiles_per_frame
     uint32_t pixels;                // width * height
     int cache_recs;                 // records actually staged (<= PT_CACHE)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         uint32_t f = tile_g / (uint32_t)a.tiles_per_frame;
                         int t = (int)(tile_g - f * (uint32_t)a.tiles_per_frame);
                         int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                        int gx = tx * 8 + (l & 7), gy = ty * 8 + (l >> 3);
+                        int gx = tx * 8 + (l & 7), gy = (ty + a.tile_y0) * 8 + (l >> 3);
                         if (gx < cam.width && gy < cam.height) {
                             primary_ray(cam, gx, gy, p.o, p.d, p.inv);
                             p.seed = pixel_seed(cam, gx, gy, a.frame_base + f * a.frame_stride);
@@ -354,10 +355,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
 // Folds the staged samples of one batch into the framebuffer, frame by frame in order:
 // final = (acc*frameCount + colour) / (frameCount + 1)   (raytrace.glsl:296), or acc + colour in SUM mode.
 __global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint32_t num_frames, uint32_t pixels,
-                                                    uint32_t frame_base, uint32_t frame_stride, uint32_t sum_mode,
-                                                    uint32_t read_prev, const float4* prev, float4* out) {
+                                                    uint32_t first_pixel, uint32_t num_pixels, uint32_t frame_base,
+                                                    uint32_t frame_stride, uint32_t sum_mode, uint32_t read_prev,
+                                                    const float4* prev, float4* out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= pixels) return;
+    if (i >= num_pixels) return;
+    i += first_pixel;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (read_prev) acc = prev[i];
     for (uint32_t j = 0; j < num_frames; j++) {

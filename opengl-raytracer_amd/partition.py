@@ -23,3 +23,13 @@ def all_frames(world: int, first_step: int, steps: int):
         base, stride, n = rank_frames(g, world, first_step, steps)
         out.extend(base + k * stride for k in range(n))
     return sorted(out)
+
+
+def band_rows(index: int, count: int, height: int):
+    """Pixel rows [r0, r1) of horizontal band `index` of `count` (the image-tile partition): bands are runs of
+    8-pixel tile rows, band i = tile rows [i*R//count, (i+1)*R//count) with R = ceil(height / 8)."""
+    if not (0 <= index < count):
+        raise ValueError("bad band")
+    R = (height + 7) // 8
+    t0, t1 = index * R // count, (index + 1) * R // count
+    return min(t0 * 8, height), min(t1 * 8, height)

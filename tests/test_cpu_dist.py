@@ -29,3 +29,14 @@ def test_two_rank_sum_reduce_matches_sequential_mean(tmp_path):
     res = np.load(out)
     assert float(res["err"]) < 1e-6            # sum/N vs running mean: fp32 rounding only
     assert float(res["rays"]) == float(res["rays_seq"])   # every frame rendered exactly once
+
+
+def test_band_rows_partition_the_image(pkg):
+    from opengl_raytracer_amd import partition
+
+    for height in (1, 7, 8, 9, 217, 1080, 2160):
+        for count in (1, 2, 3, 8):
+            rows = [partition.band_rows(i, count, height) for i in range(count)]
+            assert rows[0][0] == 0 and rows[-1][1] == height
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(count - 1))
+            assert all(r0 % 8 == 0 for r0, _ in rows if r0 < height)

@@ -359,3 +359,44 @@ def test_two_contexts_are_independent(pkg, oracle, scenes):
     assert np.array_equal(bits(ia), bits(wa)) and np.array_equal(bits(ib), bits(wb))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("size,bands", [((333, 217), 3), ((640, 360), 8), ((64, 20), 5)])
+def test_band_partition_union_equals_whole_image(pkg, oracle, gpu_ctx, scenes, size, bands):
+    """Image-tile partition (BASELINE configs[4]): each band rendered by its own call, into the rows
+    partition.band_rows() names and nowhere else; the union is bit-identical to the whole image and to the oracle."""
+    from opengl_raytracer_amd import partition
+    scene = scenes("teapot")
+    cam = pkg.make_camera(yaw=0.1)
+    W, H = size
+    gpu_ctx.upload_scene(scene)
+    whole = gpu_ctx.render(cam, pkg.make_params(W, H, frames=3))
+    want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=3))
+    assert np.array_equal(bits(whole), bits(want))
+    sentinel = np.float32(-7.0)
+    union = np.full((H, W, 4), sentinel, dtype=np.float32)
+    covered = np.zeros(H, dtype=int)
+    for g in range(bands):
+        buf = np.full((H, W, 4), sentinel, dtype=np.float32)
+        # frame_base 0 ignores the buffer's content inside the band; outside the band it must stay untouched
+        out = gpu_ctx.render(cam, pkg.make_params(W, H, frames=3, band=(g, bands)), buf)
+        r0, r1 = partition.band_rows(g, bands, H)
+        covered[r0:r1] += 1
+        assert np.all(out[:r0] == sentinel) and np.all(out[r1:] == sentinel)
+        union[r0:r1] = out[r0:r1]
+    assert np.all(covered == 1)
+    assert np.array_equal(bits(union), bits(whole))
+    # SUM mode over bands into ONE buffer
+    acc = np.zeros((H, W, 4), dtype=np.float32)
+    for g in range(bands):
+        acc = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2, flags=pkg.RT_FLAG_SUM, band=(g, bands)), acc)
+    want_sum = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2, flags=pkg.RT_FLAG_SUM))
+    assert np.array_equal(bits(acc), bits(want_sum))
+
+
+def test_band_argument_errors(pkg, gpu_ctx, scenes):
+    gpu_ctx.upload_scene(scenes("model"))
+    cam = pkg.make_camera()
+    for bad in (dict(band=(3, 3)), dict(band=(0, 2), flags=pkg.RT_FLAG_MEGAKERNEL), dict(band=(0, 2), rays_per_pixel=2)):
+        with pytest.raises(RuntimeError):
+            gpu_ctx.render(cam, pkg.make_params(64, 64, **bad))
