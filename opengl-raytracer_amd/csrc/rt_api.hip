@@ -365,6 +365,9 @@ struct rt_context {
     uint32_t* d_ref_src = nullptr;
     int built_nodes = 0;
     float last_build_ms = 0.0f;
+    // builder workspace, kept between builds (a per-frame rebuild must not pay for fresh allocations)
+    std::vector<void*> ws_ptr;
+    std::vector<size_t> ws_bytes;
 
     // per-resolution buffers
     size_t cap_slots = 0;  // queue capacity (padded pixel count)
@@ -732,6 +735,10 @@ int rt_destroy(rt_context* c) {
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     free_buffers(c);
+    for (void* p : c->ws_ptr)
+        if (p) (void)hipFree(p);
+    c->ws_ptr.clear();
+    c->ws_bytes.clear();
     dfree(c->d_frame);
     dfree(c->d_counters);
     dfree(c->d_counts);
@@ -950,16 +957,26 @@ int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vert
     float4* d_fcol = nullptr;
     uint32_t* d_root = nullptr;
     BuildState s{};
-    std::vector<void*> temps;
-    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-        if (e == hipSuccess) temps.push_back(*p);
-        return e;
+    size_t ws_next = 0;
+    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {  // slot ws_next of the cached workspace, grown on demand
+        const size_t k = ws_next++;
+        if (c->ws_ptr.size() <= k) {
+            c->ws_ptr.resize(k + 1, nullptr);
+            c->ws_bytes.resize(k + 1, 0);
+        }
+        if (c->ws_bytes[k] < bytes || !c->ws_ptr[k]) {
+            if (c->ws_ptr[k]) (void)hipFree(c->ws_ptr[k]);
+            c->ws_ptr[k] = nullptr;
+            c->ws_bytes[k] = 0;
+            const size_t want = bytes + bytes / 8 + 256;  // a little slack so that small growth does not reallocate
+            hipError_t e = hipMalloc(&c->ws_ptr[k], want);
+            if (e != hipSuccess) return e;
+            c->ws_bytes[k] = want;
+        }
+        *p = c->ws_ptr[k];
+        return hipSuccess;
     };
-    auto cleanup = [&]() {
-        for (void* p : temps) (void)hipFree(p);
-        temps.clear();
-    };
+    auto cleanup = [&]() {};
 #define BCHK(call)                                                                              \
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \

@@ -70,31 +70,44 @@ __device__ __forceinline__ int bb_bin(float c, float lo, float hi) {
     return b < 0 ? 0 : (b > BB_BINS - 1 ? BB_BINS - 1 : b);
 }
 
-// centroid, box per triangle; root bounds by atomics
+// centroid and box per triangle; root bounds by wave reduction + one atomic per wave
 __global__ __launch_bounds__(BB_BLOCK) void k_build_prep(const float* verts, const uint32_t* faces, int nf, BuildState s,
                                                          uint32_t* root_keys /*12: nmin nmax cmin cmax*/) {
     int i = blockIdx.x * BB_BLOCK + threadIdx.x;
-    if (i >= nf) return;
+    // lanes past the end carry the neutral elements of the reductions below
+    rt_vec3 lo = rt_v3(RT_INF, RT_INF, RT_INF), hi = rt_v3(-RT_INF, -RT_INF, -RT_INF), cel = lo, ceh = hi;
+    if (i < nf) {
     uint32_t ia = faces[3 * i], ib = faces[3 * i + 1], ic = faces[3 * i + 2];
     rt_vec3 a = rt_v3(verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]);
     rt_vec3 b = rt_v3(verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]);
     rt_vec3 c = rt_v3(verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]);
-    rt_vec3 lo = rt_v3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
-    rt_vec3 hi = rt_v3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
-    rt_vec3 ce = rt_v3(((a.x + b.x) + c.x) / 3.0f, ((a.y + b.y) + c.y) / 3.0f, ((a.z + b.z) + c.z) / 3.0f);  // bvh.cpp:156
+    lo = rt_v3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+    hi = rt_v3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+    const rt_vec3 ce = rt_v3(((a.x + b.x) + c.x) / 3.0f, ((a.y + b.y) + c.y) / 3.0f, ((a.z + b.z) + c.z) / 3.0f);  // bvh.cpp:156
+    cel = ceh = ce;
     s.tcen[i] = make_float4(ce.x, ce.y, ce.z, 0.0f);
     s.tmin[i] = make_float4(lo.x, lo.y, lo.z, 0.0f);
     s.tmax[i] = make_float4(hi.x, hi.y, hi.z, 0.0f);
     s.order[0][i] = (uint32_t)i;
     s.node_of[0][i] = 0;
-    const float v[12] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, ce.x, ce.y, ce.z, ce.x, ce.y, ce.z};
+    }
+    // root bounds: reduce over the wave with shuffles, then one atomic per wave and component
+    const float v[12] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, cel.x, cel.y, cel.z, ceh.x, ceh.y, ceh.z};
 #pragma unroll
     for (int k = 0; k < 12; k++) {
-        bool is_min = k < 3 || (k >= 6 && k < 9);
-        if (is_min)
-            atomicMin(&root_keys[k], bb_key(v[k]));
-        else
-            atomicMax(&root_keys[k], bb_key(v[k]));
+        const bool is_min = k < 3 || (k >= 6 && k < 9);
+        float x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float y = __shfl_xor(x, off, 64);
+            x = is_min ? fminf(x, y) : fmaxf(x, y);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (is_min)
+                atomicMin(&root_keys[k], bb_key(x));
+            else
+                atomicMax(&root_keys[k], bb_key(x));
+        }
     }
 }
 
