@@ -137,6 +137,11 @@ int rt_get_normals(rt_context* ctx, float* out_normals);
  * index the leaf-ordered arrays returned by rt_get_built_scene.  Synchronises. */
 int rt_build_scene_device(rt_context* ctx, const float* vertices, int32_t num_vertices, const uint32_t* faces,
                           int32_t num_faces, const float* face_colours);
+/* Per-frame rebuild for an animated mesh (no counterpart in the reference): same faces and colours as the last
+ * rt_build_scene_device, new vertex positions read from the DEVICE pointer d_vertices (num_vertices x 3 floats, copied
+ * on the context's stream).  Reuses every buffer of the previous build: no allocation, no host validation, no upload.
+ * Synchronises (the level loop reads one counter pair per level). */
+int rt_rebuild_scene_device(rt_context* ctx, const float* d_vertices);
 /* Downloads the device-built scene in the layout of rt_scene (so that any other implementation of the path can
  * render the very same tree): nodes num_nodes x 12, triv0/1/2 and colours num_tris x 4 in leaf order, tri_src
  * = face index of each leaf-ordered triangle, build_ms = device time of the build.  Any pointer may be NULL;

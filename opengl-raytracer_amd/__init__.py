@@ -114,6 +114,7 @@ HIP_SYMBOLS = [
     "rt_upload_scene",
     "rt_get_normals",
     "rt_build_scene_device",
+    "rt_rebuild_scene_device",
     "rt_get_built_scene",
     "rt_raytrace_frame",
     "rt_render_device",
@@ -177,6 +178,7 @@ def load_hip() -> C.CDLL:
         lib.rt_upload_scene.argtypes = [vp, C.POINTER(RtScene)]
         lib.rt_get_normals.argtypes = [vp, c_float_p]
         lib.rt_build_scene_device.argtypes = [vp, c_float_p, C.c_int32, c_uint32_p, C.c_int32, c_float_p]
+        lib.rt_rebuild_scene_device.argtypes = [vp, vp]
         lib.rt_get_built_scene.argtypes = [vp, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                            c_int32_p, c_float_p]
         lib.rt_raytrace_frame.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, vp, vp]
@@ -196,6 +198,51 @@ def load_hip() -> C.CDLL:
                 fn.restype = C.c_int
         _hip = lib
     return _hip
+
+
+class DeviceBuffer:
+    """Plain device memory from the HIP runtime the render library is linked against, for callers that hold no other
+    GPU library (the tests).  Allocated on the current HIP device."""
+
+    _rt = None
+
+    @classmethod
+    def _runtime(cls):
+        if cls._rt is None:
+            load_hip()                                   # makes sure the runtime below is the one librt_hip.so uses
+            rt = C.CDLL("libamdhip64.so.7")
+            rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            rt.hipFree.argtypes = [C.c_void_p]
+            rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            cls._rt = rt
+        return cls._rt
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        if self._runtime().hipMalloc(C.byref(p), self.nbytes) != 0 or not p.value:
+            raise RuntimeError(f"hipMalloc of {nbytes} bytes failed")
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        if cls._runtime().hipMemcpy(buf.ptr, a.ctypes.data, a.nbytes, 1) != 0:   # hipMemcpyHostToDevice
+            raise RuntimeError("hipMemcpy to the device failed")
+        return buf
+
+    def to_array(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        if self._runtime().hipMemcpy(out.ctypes.data, self.ptr, out.nbytes, 2) != 0:  # hipMemcpyDeviceToHost
+            raise RuntimeError("hipMemcpy from the device failed")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._runtime().hipFree(self.ptr)
+            self.ptr = None
 
 
 def fptr(a: np.ndarray):
@@ -339,9 +386,9 @@ class RenderContext:
         self._check(self.lib.rt_upload_scene(self.ctx, C.byref(s)), "rt_upload_scene")
         self.num_tris = scene.num_tris
 
-    def build_scene_device(self, vertices: np.ndarray, faces: np.ndarray, face_colours: np.ndarray):
-        """GPU binned-SAH build; returns the built scene downloaded in the reference layout (a Scene) and the
-        device build time in milliseconds."""
+    def build_scene_device(self, vertices: np.ndarray, faces: np.ndarray, face_colours: np.ndarray, download: bool = True):
+        """GPU binned-SAH build; returns the built scene downloaded in the reference layout (a Scene, or None with
+        download=False) and the device build time in milliseconds."""
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         f = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
         col = np.ascontiguousarray(face_colours, dtype=np.float32).reshape(-1, 4)
@@ -349,9 +396,20 @@ class RenderContext:
         self._check(self.lib.rt_build_scene_device(self.ctx, fptr(v), v.shape[0], f.ctypes.data_as(c_uint32_p), f.shape[0],
                                                    fptr(col)), "rt_build_scene_device")
         self.num_tris = f.shape[0]
+        return self.get_built_scene(download)
+
+    def rebuild_scene_device(self, d_vertices_ptr: int, download: bool = False):
+        """Rebuild with the faces and colours of the last build_scene_device and new vertex positions read from a
+        device pointer (num_vertices x 3 floats)."""
+        self._check(self.lib.rt_rebuild_scene_device(self.ctx, C.c_void_p(d_vertices_ptr)), "rt_rebuild_scene_device")
+        return self.get_built_scene(download)
+
+    def get_built_scene(self, download: bool = True):
         n, t, ms = C.c_int32(), C.c_int32(), C.c_float()
         self._check(self.lib.rt_get_built_scene(self.ctx, C.byref(n), C.byref(t), None, None, None, None, None, None, C.byref(ms)),
                     "rt_get_built_scene")
+        if not download:
+            return None, ms.value
         nodes = np.empty((n.value, 12), dtype=np.float32)
         v0, v1, v2, cc = (np.empty((t.value, 4), dtype=np.float32) for _ in range(4))
         src = np.empty(t.value, dtype=np.int32)

@@ -345,6 +345,18 @@ struct EventPair {
     int cls;
 };
 
+struct BuiltData {
+    int nv = 0, nf = 0, nv_cap = 0, nf_cap = 0;
+    float* d_verts = nullptr;
+    uint32_t* d_faces = nullptr;
+    float4* d_fcol = nullptr;
+    BuildState s{};
+    int cur = 0;           // which of the ping-pong order arrays holds the final order
+    int out_cap = 0;       // faces the output buffers (d_nodes, d_tris, d_shade) were sized for; 0 = not from a build
+    int ref_cap = 0;       // faces the reference-layout buffers were sized for
+    bool ref_valid = false;
+};
+
 struct rt_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -359,7 +371,11 @@ struct rt_context {
     float4* d_shade = nullptr;
     int num_tris = 0;
     int max_depth = 0;
-    // reference-layout copy of a scene built on the device (rt_build_scene_device), for rt_get_built_scene
+    // a scene built on the device (rt_build_scene_device): topology and vertices kept for rebuilds
+    BuiltData bd;
+    int build_gen = 2;  // RT_BUILD_GEN=1 selects the first-generation level loop (no small-subtree kernel)
+    hipEvent_t build_ev0 = nullptr, build_ev1 = nullptr;
+    // its reference-layout copy, made on demand for rt_get_built_scene
     float* d_ref_nodes = nullptr;
     float4 *d_ref_v0 = nullptr, *d_ref_v1 = nullptr, *d_ref_v2 = nullptr, *d_ref_col = nullptr;
     uint32_t* d_ref_src = nullptr;
@@ -427,16 +443,23 @@ static void dfree(T*& p) {
     p = nullptr;
 }
 
-static void free_scene(rt_context* c) {
-    dfree(c->d_nodes);
-    dfree(c->d_tris);
-    dfree(c->d_shade);
+static void free_ref(rt_context* c) {
     dfree(c->d_ref_nodes);
     dfree(c->d_ref_v0);
     dfree(c->d_ref_v1);
     dfree(c->d_ref_v2);
     dfree(c->d_ref_col);
     dfree(c->d_ref_src);
+    c->bd.ref_cap = 0;
+    c->bd.ref_valid = false;
+}
+
+static void free_scene(rt_context* c) {
+    dfree(c->d_nodes);
+    dfree(c->d_tris);
+    dfree(c->d_shade);
+    free_ref(c);
+    c->bd.out_cap = 0;
     c->built_nodes = 0;
     c->has_scene = false;
 }
@@ -722,6 +745,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     }
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_PATHS_GEN")) c->use_paths2 = atoi(e) == 2;
+    if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     hipDeviceProp_t prop;
     c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
                      ? prop.multiProcessorCount : 256;
@@ -739,6 +763,11 @@ int rt_destroy(rt_context* c) {
         if (p) (void)hipFree(p);
     c->ws_ptr.clear();
     c->ws_bytes.clear();
+    dfree(c->bd.d_verts);
+    dfree(c->bd.d_faces);
+    dfree(c->bd.d_fcol);
+    if (c->build_ev0) (void)hipEventDestroy(c->build_ev0);
+    if (c->build_ev1) (void)hipEventDestroy(c->build_ev1);
     dfree(c->d_frame);
     dfree(c->d_counters);
     dfree(c->d_counts);
@@ -937,26 +966,16 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
 }
 
 // ---- GPU BVH build (rt_build.h) ---------------------------------------------------------------------------
-int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vertices, const uint32_t* faces,
-                          int32_t num_faces, const float* face_colours) {
-    if (!c) return RT_EINVAL;
-    if (!vertices || !faces || !face_colours) return fail(c, RT_EINVAL, "NULL argument");
-    if (num_vertices < 1 || num_faces < 1) return fail(c, RT_EINVAL, "need at least one vertex and one face");
-    if ((int64_t)num_faces > (int64_t)0x3ffffff0) return fail(c, RT_ELIMIT, "too many faces");
-    for (int64_t i = 0; i < (int64_t)num_faces * 3; i++)
-        if (faces[i] >= (uint32_t)num_vertices) return fail(c, RT_EINVAL, "face %lld references vertex %u of %d", (long long)(i / 3), faces[i], num_vertices);
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_scene(c);
-    const int nf = num_faces, max_nodes = 2 * nf;
-    const size_t max_active = (size_t)nf / 2 + 2;
+// Builds from the topology kept in the context (c->bd) and the vertices in c->bd.d_verts.  All device memory comes from
+// the cached workspace or from output buffers sized for the worst case, so that a rebuild allocates nothing.
+static int build_core(rt_context* c) {
+    BuiltData& bd = c->bd;
+    const int nf = bd.nf, max_nodes = 2 * nf;
+    const bool v1 = c->build_gen == 1;  // first-generation level loop all the way down (kept as the cross-check)
+    const int small_max = v1 ? 0 : BS_MAX;
+    const size_t max_active = v1 ? (size_t)nf / 2 + 2 : (size_t)nf / (size_t)BS_MAX + 1024;
     hipStream_t st = c->stream;
-
-    float* d_verts = nullptr;
-    uint32_t* d_faces = nullptr;
-    float4* d_fcol = nullptr;
-    uint32_t* d_root = nullptr;
-    BuildState s{};
+    BuildState& s = bd.s;
     size_t ws_next = 0;
     auto dalloc = [&](void** p, size_t bytes) -> hipError_t {  // slot ws_next of the cached workspace, grown on demand
         const size_t k = ws_next++;
@@ -976,19 +995,15 @@ int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vert
         *p = c->ws_ptr[k];
         return hipSuccess;
     };
-    auto cleanup = [&]() {};
 #define BCHK(call)                                                                              \
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
-            cleanup();                                                                          \
             free_scene(c);                                                                      \
             return fail(c, RT_EDEVICE, "%s: %s", #call, hipGetErrorString(e_));                 \
         }                                                                                       \
     } while (0)
-    BCHK(dalloc((void**)&d_verts, (size_t)num_vertices * 3 * sizeof(float)));
-    BCHK(dalloc((void**)&d_faces, (size_t)nf * 3 * sizeof(uint32_t)));
-    BCHK(dalloc((void**)&d_fcol, (size_t)nf * sizeof(float4)));
+    uint32_t* d_root = nullptr;
     BCHK(dalloc((void**)&d_root, 12 * sizeof(uint32_t)));
     BCHK(dalloc((void**)&s.tcen, (size_t)nf * sizeof(float4)));
     BCHK(dalloc((void**)&s.tmin, (size_t)nf * sizeof(float4)));
@@ -1006,70 +1021,89 @@ int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vert
     for (auto pp : nints) BCHK(dalloc((void**)pp, (size_t)max_nodes * sizeof(int32_t)));
     BCHK(dalloc((void**)&s.bins, max_active * BB_NODE_WORDS * sizeof(uint32_t)));
     BCHK(dalloc((void**)&s.counters, 8 * sizeof(int32_t)));
+    BCHK(dalloc((void**)&s.small, ((size_t)nf / 2 + 2) * sizeof(int32_t)));
+    BCHK(dalloc((void**)&s.scratch, (size_t)nf * 4 * sizeof(float4)));
 
-    BCHK(hipMemcpyAsync(d_verts, vertices, (size_t)num_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, st));
-    BCHK(hipMemcpyAsync(d_faces, faces, (size_t)nf * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    BCHK(hipMemcpyAsync(d_fcol, face_colours, (size_t)nf * sizeof(float4), hipMemcpyHostToDevice, st));
+    // output buffers, sized for the worst case (nf - 1 inner nodes) and kept while the face count fits
+    if (bd.out_cap < nf || !c->d_nodes || !c->d_tris || !c->d_shade) {
+        free_scene(c);
+        BCHK(hipMalloc(&c->d_nodes, (size_t)nf * 4 * sizeof(float4)));
+        BCHK(hipMalloc(&c->d_tris, (size_t)nf * 4 * sizeof(float4)));
+        BCHK(hipMalloc(&c->d_shade, (size_t)nf * 2 * sizeof(float4)));
+        bd.out_cap = nf;
+    }
+    c->has_scene = false;
+    bd.ref_valid = false;
+
     const uint32_t root_init[12] = {BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF,
                                     BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF};
     BCHK(hipMemcpyAsync(d_root, root_init, sizeof root_init, hipMemcpyHostToDevice, st));
     BCHK(hipStreamSynchronize(st));
 
-    hipEvent_t ev0, ev1;
-    BCHK(hipEventCreate(&ev0));
-    BCHK(hipEventCreate(&ev1));
-    BCHK(hipEventRecord(ev0, st));
+    if (!c->build_ev0) {
+        BCHK(hipEventCreate(&c->build_ev0));
+        BCHK(hipEventCreate(&c->build_ev1));
+    }
+    BCHK(hipEventRecord(c->build_ev0, st));
     const dim3 blk(BB_BLOCK), grid_t((nf + BB_BLOCK - 1) / BB_BLOCK);
-    hipLaunchKernelGGL(k_build_prep, grid_t, blk, 0, st, d_verts, d_faces, nf, s, d_root);
+    // positions per workgroup in the level loop: enough workgroups to fill the chip, at most BB_MAX_SPAN
+    int span = ((nf / 2048) / BB_BLOCK) * BB_BLOCK;
+    span = span < BB_BLOCK ? BB_BLOCK : (span > BB_MAX_SPAN ? BB_MAX_SPAN : span);
+    const dim3 grid_s((nf + span - 1) / span);
+    hipLaunchKernelGGL(k_build_prep, grid_t, blk, 0, st, bd.d_verts, bd.d_faces, nf, s, d_root);
     hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, st, s, d_root, nf);
     int cur = 0, cur_list = 0, levels = 0;
-    int32_t h_counters[4] = {0, 0, 0, 0};
+    int32_t h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         BCHK(hipMemcpyAsync(h_counters, s.counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));
         const int active = h_counters[2];
         if (active <= 0 || levels > BB_MAX_DEPTH + 1) break;
+        if ((size_t)active > max_active) {
+            free_scene(c);
+            return fail(c, RT_EDEVICE, "builder: %d active nodes exceed the workspace for %zu", active, max_active);
+        }
         const size_t words = (size_t)active * BB_NODE_WORDS;
         hipLaunchKernelGGL(k_build_clear_bins, dim3((unsigned)((words + BB_BLOCK - 1) / BB_BLOCK)), blk, 0, st, s.bins, words);
         BCHK(hipMemsetAsync(s.counters + 2, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_build_bin, grid_t, blk, 0, st, s, cur, nf);
-        hipLaunchKernelGGL(k_build_split, dim3((active + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, cur_list, active, max_nodes);
-        hipLaunchKernelGGL(k_build_partition, grid_t, blk, 0, st, s, cur, nf);
+        if (v1)
+            hipLaunchKernelGGL(k_build_bin, grid_t, blk, 0, st, s, cur, nf);
+        else
+            hipLaunchKernelGGL(k_build_bin2, grid_s, blk, 0, st, s, cur, nf, span);
+        hipLaunchKernelGGL(k_build_split, dim3((active + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, cur_list, active, max_nodes, small_max,
+                           BS_MIN_DEPTH);
+        if (v1)
+            hipLaunchKernelGGL(k_build_partition, grid_t, blk, 0, st, s, cur, nf);
+        else
+            hipLaunchKernelGGL(k_build_partition2, grid_s, blk, 0, st, s, cur, nf, span);
         BCHK(hipGetLastError());
         cur ^= 1;
         cur_list ^= 1;
         levels++;
     }
+    if (h_counters[4] > 0) {
+        hipLaunchKernelGGL(k_build_small, dim3(h_counters[4]), dim3(64), 0, st, s, cur, h_counters[4]);
+        BCHK(hipGetLastError());
+        BCHK(hipMemcpyAsync(h_counters, s.counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
+        BCHK(hipStreamSynchronize(st));
+    }
     const int num_nodes = h_counters[0], num_recs = h_counters[1], depth = h_counters[3];
-
-    // persistent outputs
-    BCHK(hipMalloc(&c->d_nodes, (size_t)(num_recs ? num_recs : 1) * 4 * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_tris, (size_t)nf * 4 * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_shade, (size_t)nf * 2 * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_ref_nodes, (size_t)num_nodes * 12 * sizeof(float)));
-    BCHK(hipMalloc(&c->d_ref_v0, (size_t)nf * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_ref_v1, (size_t)nf * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_ref_v2, (size_t)nf * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_ref_col, (size_t)nf * sizeof(float4)));
-    BCHK(hipMalloc(&c->d_ref_src, (size_t)nf * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_build_emit_nodes, dim3((num_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, num_nodes, c->d_ref_nodes, c->d_nodes);
-    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, s, cur, nf, d_verts, d_faces, d_fcol, c->d_tris, c->d_ref_v0, c->d_ref_v1,
-                       c->d_ref_v2, c->d_ref_col);
-    hipLaunchKernelGGL(k_normals, dim3((nf + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->d_ref_v0, c->d_ref_v1, c->d_ref_v2,
-                       c->d_ref_col, c->d_shade, nf);
-    BCHK(hipMemcpyAsync(c->d_ref_src, s.order[cur], (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    BCHK(hipEventRecord(ev1, st));
+    if (num_nodes > max_nodes || num_recs > nf) {
+        free_scene(c);
+        return fail(c, RT_EDEVICE, "builder: %d nodes / %d records for %d faces", num_nodes, num_recs, nf);
+    }
+    hipLaunchKernelGGL(k_build_emit_recs, dim3((num_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, num_nodes, c->d_nodes);
+    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, s, cur, nf, bd.d_verts, bd.d_faces, bd.d_fcol, c->d_tris, c->d_shade);
+    BCHK(hipEventRecord(c->build_ev1, st));
     float4 rlo, rhi;
     BCHK(hipMemcpyAsync(&rlo, s.nmin, sizeof rlo, hipMemcpyDeviceToHost, st));
     BCHK(hipMemcpyAsync(&rhi, s.nmax, sizeof rhi, hipMemcpyDeviceToHost, st));
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(st));
-    (void)hipEventElapsedTime(&c->last_build_ms, ev0, ev1);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    cleanup();
+    (void)hipEventElapsedTime(&c->last_build_ms, c->build_ev0, c->build_ev1);
 #undef BCHK
 
+    bd.cur = cur;
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
     c->sc.shade = c->d_shade;
@@ -1079,21 +1113,87 @@ int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vert
     c->sc.num_tris = nf;
     c->num_tris = nf;
     c->max_depth = depth;
-    c->cache_recs = num_recs < RT_BFS_PREFIX ? num_recs : RT_BFS_PREFIX;  // records are numbered level by level
+    c->cache_recs = num_recs < RT_BFS_PREFIX ? num_recs : RT_BFS_PREFIX;  // the first records are the top levels
     c->built_nodes = num_nodes;
     c->has_scene = true;
     if (c->max_depth > RT_LDS_STACK && (size_t)(c->max_depth - RT_LDS_STACK + 1) > c->spill_entries) free_buffers(c);
     return RT_OK;
 }
 
+int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vertices, const uint32_t* faces,
+                          int32_t num_faces, const float* face_colours) {
+    if (!c) return RT_EINVAL;
+    if (!vertices || !faces || !face_colours) return fail(c, RT_EINVAL, "NULL argument");
+    if (num_vertices < 1 || num_faces < 1) return fail(c, RT_EINVAL, "need at least one vertex and one face");
+    if ((int64_t)num_faces > (int64_t)0x3ffffff0) return fail(c, RT_ELIMIT, "too many faces");
+    for (int64_t i = 0; i < (int64_t)num_faces * 3; i++)
+        if (faces[i] >= (uint32_t)num_vertices) return fail(c, RT_EINVAL, "face %lld references vertex %u of %d", (long long)(i / 3), faces[i], num_vertices);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    BuiltData& bd = c->bd;
+    if (bd.nv_cap < num_vertices) {
+        dfree(bd.d_verts);
+        bd.nv_cap = 0;
+        HIPCHK(c, hipMalloc(&bd.d_verts, (size_t)num_vertices * 3 * sizeof(float)));
+        bd.nv_cap = num_vertices;
+    }
+    if (bd.nf_cap < num_faces) {
+        dfree(bd.d_faces);
+        dfree(bd.d_fcol);
+        bd.nf_cap = 0;
+        HIPCHK(c, hipMalloc(&bd.d_faces, (size_t)num_faces * 3 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&bd.d_fcol, (size_t)num_faces * sizeof(float4)));
+        bd.nf_cap = num_faces;
+    }
+    bd.nv = num_vertices;
+    bd.nf = num_faces;
+    HIPCHK(c, hipMemcpyAsync(bd.d_verts, vertices, (size_t)num_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bd.d_faces, faces, (size_t)num_faces * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bd.d_fcol, face_colours, (size_t)num_faces * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return build_core(c);
+}
+
+int rt_rebuild_scene_device(rt_context* c, const float* d_vertices) {
+    if (!c) return RT_EINVAL;
+    if (!d_vertices) return fail(c, RT_EINVAL, "d_vertices is NULL");
+    BuiltData& bd = c->bd;
+    if (bd.nf <= 0 || !bd.d_faces || !c->built_nodes) return fail(c, RT_ENOSCENE, "rt_rebuild_scene_device needs a scene built by rt_build_scene_device");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(bd.d_verts, d_vertices, (size_t)bd.nv * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return build_core(c);
+}
+
 int rt_get_built_scene(rt_context* c, int32_t* num_nodes, int32_t* num_tris, float* nodes, float* triv0, float* triv1,
                        float* triv2, float* colours, int32_t* tri_src, float* build_ms) {
     if (!c) return RT_EINVAL;
-    if (!c->has_scene || !c->d_ref_nodes) return fail(c, RT_ENOSCENE, "the current scene was not built on the device");
+    if (!c->has_scene || !c->built_nodes) return fail(c, RT_ENOSCENE, "the current scene was not built on the device");
     if (num_nodes) *num_nodes = c->built_nodes;
     if (num_tris) *num_tris = c->num_tris;
     if (build_ms) *build_ms = c->last_build_ms;
-    const size_t T = (size_t)c->num_tris;
+    if (!nodes && !triv0 && !triv1 && !triv2 && !colours && !tri_src) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    BuiltData& bd = c->bd;
+    const int nf = bd.nf;
+    const size_t T = (size_t)nf;
+    if (!bd.ref_valid) {  // the reference-layout copy is made on the first download after a build
+        if (bd.ref_cap < nf) {
+            free_ref(c);
+            HIPCHK(c, hipMalloc(&c->d_ref_nodes, (size_t)2 * T * 12 * sizeof(float)));
+            HIPCHK(c, hipMalloc(&c->d_ref_v0, T * sizeof(float4)));
+            HIPCHK(c, hipMalloc(&c->d_ref_v1, T * sizeof(float4)));
+            HIPCHK(c, hipMalloc(&c->d_ref_v2, T * sizeof(float4)));
+            HIPCHK(c, hipMalloc(&c->d_ref_col, T * sizeof(float4)));
+            HIPCHK(c, hipMalloc(&c->d_ref_src, T * sizeof(uint32_t)));
+            bd.ref_cap = nf;
+        }
+        const dim3 blk(BB_BLOCK);
+        hipLaunchKernelGGL(k_build_emit_ref_nodes, dim3((c->built_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, c->stream, bd.s, c->built_nodes,
+                           c->d_ref_nodes);
+        hipLaunchKernelGGL(k_build_emit_ref_tris, dim3((nf + BB_BLOCK - 1) / BB_BLOCK), blk, 0, c->stream, bd.s, bd.cur, nf, bd.d_verts,
+                           bd.d_faces, bd.d_fcol, c->d_ref_v0, c->d_ref_v1, c->d_ref_v2, c->d_ref_col, c->d_ref_src);
+        HIPCHK(c, hipGetLastError());
+        bd.ref_valid = true;
+    }
     if (nodes) HIPCHK(c, hipMemcpyAsync(nodes, c->d_ref_nodes, (size_t)c->built_nodes * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (triv0) HIPCHK(c, hipMemcpyAsync(triv0, c->d_ref_v0, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (triv1) HIPCHK(c, hipMemcpyAsync(triv1, c->d_ref_v1, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));

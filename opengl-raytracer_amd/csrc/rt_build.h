@@ -14,8 +14,11 @@
 //                two children (breadth-first ids) and the node's record id;
 //   k_partition  each triangle of a split node moves to its child's segment; destinations come from per-child
 //                cursors, aggregated per wave (ballot + mbcnt, one atomic per wave and child).
+// Once a node has at most BS_MAX triangles (and lies below the levels that the render kernels stage in LDS) it
+// leaves the level loop: k_build_small finishes its whole subtree inside one wavefront, in LDS, with the very same
+// binning, cost and partition arithmetic, so the tree is the one the level loop alone would have produced.
 // The bins, bounds and split decisions are deterministic; the order of triangles INSIDE a leaf depends on the
-// atomics' arrival order.
+// atomics' arrival order in the level loop.
 #ifndef RT_BUILD_H
 #define RT_BUILD_H
 
@@ -60,7 +63,10 @@ struct BuildState {
     int32_t* active[2];  // active node lists (ping-pong)
     uint32_t* bins;      // active_count x BB_NODE_WORDS
     int32_t* cursors;    // per node: next free position of its segment during partition
-    int32_t* counters;   // [0] nodes allocated, [1] records allocated, [2] next level's active count, [3] max depth
+    int32_t* counters;   // [0] nodes allocated, [1] records allocated, [2] next level's active count, [3] max depth,
+                         // [4] small subtree roots
+    int32_t* small;      // roots handed to k_build_small
+    float4* scratch;     // 4 float4 per triangle position: node entries of a small subtree before they get ids
 };
 
 __device__ __forceinline__ int bb_bin(float c, float lo, float hi) {
@@ -102,11 +108,15 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_prep(const float* verts, con
             float y = __shfl_xor(x, off, 64);
             x = is_min ? fminf(x, y) : fmaxf(x, y);
         }
+        // bounds only ever tighten, so a (possibly stale) read that already covers x makes the atomic unnecessary;
+        // without the test all waves serialise on twelve addresses
         if ((threadIdx.x & 63) == 0) {
-            if (is_min)
-                atomicMin(&root_keys[k], bb_key(x));
-            else
-                atomicMax(&root_keys[k], bb_key(x));
+            const uint32_t key = bb_key(x), seen = __atomic_load_n(&root_keys[k], __ATOMIC_RELAXED);
+            if (is_min) {
+                if (key < seen) atomicMin(&root_keys[k], key);
+            } else {
+                if (key > seen) atomicMax(&root_keys[k], key);
+            }
         }
     }
 }
@@ -130,6 +140,7 @@ __global__ void k_build_root(BuildState s, const uint32_t* root_keys, int nf) {
     s.counters[1] = 0;
     s.counters[2] = act ? 1 : 0;
     s.counters[3] = 0;
+    s.counters[4] = 0;
 }
 
 __global__ __launch_bounds__(BB_BLOCK) void k_build_clear_bins(uint32_t* bins, size_t words) {
@@ -199,7 +210,8 @@ __device__ __forceinline__ float bb_area6(const float* lo, const float* hi) {
 }
 
 // One lane per active node: choose the split, create the children.
-__global__ __launch_bounds__(BB_BLOCK) void k_build_split(BuildState s, int cur_list, int num_active, int max_nodes) {
+__global__ __launch_bounds__(BB_BLOCK) void k_build_split(BuildState s, int cur_list, int num_active, int max_nodes,
+                                                          int small_max, int small_min_depth) {
     int a = blockIdx.x * BB_BLOCK + threadIdx.x;
     if (a >= num_active) return;
     const int node = s.active[cur_list][a];
@@ -303,7 +315,9 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_split(BuildState s, int cur_
         s.cursors[c] = side ? start + best_nl : start;
         bool act = cnt >= 2 && depth + 1 < BB_MAX_DEPTH;
         int slot = -1;
-        if (act) {
+        if (act && cnt <= small_max && depth + 1 >= small_min_depth) {
+            s.small[atomicAdd(&s.counters[4], 1)] = c;
+        } else if (act) {
             slot = atomicAdd(&s.counters[2], 1);
             s.active[cur_list ^ 1][slot] = c;
         }
@@ -346,26 +360,403 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_partition(BuildState s, int 
     }
 }
 
+// ---- level loop, second generation: a workgroup owns `span` consecutive positions and walks the node segments in it
+// ---------------------------------------------------------------------------------------------------------------------
+// Every node owns a contiguous segment of positions, so a workgroup's range is a short sequence of segments.  Each
+// segment of an active node is binned into LDS and flushed once: the number of global atomics per level is
+// (segments x bins) instead of (triangles x 21), and top levels no longer serialise on a few hot addresses.
+__global__ __launch_bounds__(BB_BLOCK) void k_build_bin2(BuildState s, int cur, int n, int span) {
+    __shared__ uint32_t l_bins[BB_NODE_WORDS];
+    const int b0 = blockIdx.x * span, b1 = min(n, b0 + span);
+    int pos = b0;
+    while (pos < b1) {
+        const int node = s.node_of[cur][pos];
+        int end = min(b1, s.nstart[node] + s.ncount[node]);
+        if (end <= pos) end = pos + 1;  // cannot happen; guarantees progress
+        const int slot = s.nslot[node];
+        if (slot >= 0) {
+            for (int k = threadIdx.x; k < BB_NODE_WORDS; k += BB_BLOCK) {
+                uint32_t w = (uint32_t)(k % BB_WORDS);
+                l_bins[k] = w == 0 ? 0u : (w <= 3 ? BB_KEY_POS_INF : BB_KEY_NEG_INF);
+            }
+            __syncthreads();
+            const float4 c0 = s.cmin[node], c1 = s.cmax[node];
+            for (int i = pos + (int)threadIdx.x; i < end; i += BB_BLOCK) {
+                const uint32_t t = s.order[cur][i];
+                const float4 ce = s.tcen[t], lo = s.tmin[t], hi = s.tmax[t];
+                const int b[3] = {bb_bin(ce.x, c0.x, c1.x), bb_bin(ce.y, c0.y, c1.y), bb_bin(ce.z, c0.z, c1.z)};
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) bb_accumulate(l_bins + (ax * BB_BINS + b[ax]) * BB_WORDS, lo, hi);
+            }
+            __syncthreads();
+            uint32_t* g = s.bins + (size_t)slot * BB_NODE_WORDS;
+            for (int k = threadIdx.x; k < BB_NODE_WORDS; k += BB_BLOCK) {
+                const uint32_t w = (uint32_t)(k % BB_WORDS), v = l_bins[k];
+                if (w == 0) {
+                    if (v) atomicAdd(&g[k], v);
+                } else if (w <= 3) {
+                    if (v != BB_KEY_POS_INF) atomicMin(&g[k], v);
+                } else {
+                    if (v != BB_KEY_NEG_INF) atomicMax(&g[k], v);
+                }
+            }
+            __syncthreads();
+        }
+        pos = end;
+    }
+}
+
+#define BB_MAX_SPAN 2048
+// Partition with one cursor update per (workgroup, segment): lefts are counted per 64-position chunk, prefix-summed in
+// LDS, and the segment's part of the workgroup moves as two stable runs.
+__global__ __launch_bounds__(BB_BLOCK) void k_build_partition2(BuildState s, int cur, int n, int span) {
+    __shared__ int l_cnt[BB_MAX_SPAN / 64];
+    __shared__ int l_base[2];
+    const int b0 = blockIdx.x * span, b1 = min(n, b0 + span);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pos = b0;
+    while (pos < b1) {
+        const int node = s.node_of[cur][pos];
+        int end = min(b1, s.nstart[node] + s.ncount[node]);
+        if (end <= pos) end = pos + 1;
+        const int sp = s.nsplit[node];
+        if (sp < 0) {
+            for (int i = pos + (int)threadIdx.x; i < end; i += BB_BLOCK) {
+                s.order[cur ^ 1][i] = s.order[cur][i];
+                s.node_of[cur ^ 1][i] = node;
+            }
+        } else {
+            const int ax = sp & 3, bin = sp >> 2, len = end - pos, child0 = s.nchild[node];
+            const float4 c0 = s.cmin[node], c1 = s.cmax[node];
+            const float lo = ax == 0 ? c0.x : (ax == 1 ? c0.y : c0.z), hi = ax == 0 ? c1.x : (ax == 1 ? c1.y : c1.z);
+            uint32_t rightbits = 0;
+            int k = 0;
+            for (int cb = wave * 64; cb < len; cb += BB_BLOCK, k++) {
+                const int i = pos + cb + lane;
+                const bool in = i < end;
+                bool right = false;
+                if (in) {
+                    const float4 ce = s.tcen[s.order[cur][i]];
+                    right = bb_bin(ax == 0 ? ce.x : (ax == 1 ? ce.y : ce.z), lo, hi) > bin;
+                }
+                const unsigned long long bl = __builtin_amdgcn_ballot_w64(in && !right);
+                if (lane == 0) l_cnt[cb >> 6] = (int)__builtin_popcountll(bl);
+                rightbits |= (right ? 1u : 0u) << k;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int chunks = (len + 63) >> 6;
+                int tot = 0;
+                for (int c = 0; c < chunks; c++) {
+                    const int v = l_cnt[c];
+                    l_cnt[c] = tot;
+                    tot += v;
+                }
+                l_base[0] = tot ? atomicAdd(&s.cursors[child0], tot) : 0;
+                l_base[1] = len - tot ? atomicAdd(&s.cursors[child0 + 1], len - tot) : 0;
+            }
+            __syncthreads();
+            k = 0;
+            for (int cb = wave * 64; cb < len; cb += BB_BLOCK, k++) {
+                const int i = pos + cb + lane;
+                const bool in = i < end, right = ((rightbits >> k) & 1u) != 0;
+                const unsigned long long bl = __builtin_amdgcn_ballot_w64(in && !right);
+                const unsigned long long br = __builtin_amdgcn_ballot_w64(in && right);
+                const unsigned long long mine = right ? br : bl;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                const int lefts_before = l_cnt[cb >> 6];
+                if (in) {
+                    const int dest = right ? l_base[1] + (cb - lefts_before) + rank : l_base[0] + lefts_before + rank;
+                    s.order[cur ^ 1][dest] = s.order[cur][i];
+                    s.node_of[cur ^ 1][dest] = child0 + (right ? 1 : 0);
+                }
+            }
+            __syncthreads();
+        }
+        pos = end;
+    }
+}
+
+// ---- small subtrees: one wavefront finishes a node of at most BS_MAX triangles -------------------------------------
+#define BS_MAX 256        // triangles per small subtree
+#define BS_DIRECT 16      // at most this many triangles: candidates are evaluated straight from the triangles
+#define BS_STACK 36       // pending right siblings, one per level below the root (depth cap 32)
+#define BS_MIN_DEPTH 9    // the level loop keeps the levels whose records the render kernels stage in LDS
+
+__device__ __forceinline__ float bs_sel(int ax, float x, float y, float z) { return ax == 0 ? x : (ax == 1 ? y : z); }
+
+struct SmallNode {  // wave-uniform description of the node being worked on
+    float lo[3], hi[3];    // box
+    float clo[3], chi[3];  // centroid bounds (the binning interval)
+    int id, depth, a, cnt; // local id, depth, first position (relative) and triangle count
+};
+
+__device__ __forceinline__ void bs_write_entry(float4* sn, int id, const float* lo, const float* hi, int child, int a, int cnt, int rec) {
+    sn[2 * id] = make_float4(lo[0], lo[1], lo[2], rt_u2f((uint32_t)child));
+    sn[2 * id + 1] = make_float4(hi[0], hi[1], hi[2], rt_u2f((uint32_t)a | ((uint32_t)cnt << 12) | ((uint32_t)rec << 24)));
+}
+
+__global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int num_small) {
+    __shared__ float t_ce[3][BS_MAX], t_lo[3][BS_MAX], t_hi[3][BS_MAX];  // triangle data by slot (initial position)
+    __shared__ uint32_t t_id[BS_MAX];                                       // face index by slot
+    __shared__ uint16_t l_idx[BS_MAX];                                      // position -> slot
+    __shared__ uint16_t l_leaf[BS_MAX];                                     // position -> local id of the node it ends in
+    __shared__ uint32_t l_bins[BB_NODE_WORDS];
+    __shared__ uint32_t l_tb[BS_DIRECT];
+    __shared__ float l_stk[BS_STACK][16];
+    __shared__ int l_alloc[2];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= num_small) return;
+    const int root = s.small[blockIdx.x];
+    const int start = s.nstart[root], n = s.ncount[root];
+    if (n > BS_MAX || n < 2) return;  // cannot happen (k_build_split hands over 2..BS_MAX triangles)
+    float4* sn = s.scratch + (size_t)start * 4;
+
+    for (int p = lane; p < n; p += 64) {
+        const uint32_t t = s.order[cur][start + p];
+        const float4 ce = s.tcen[t], lo = s.tmin[t], hi = s.tmax[t];
+        t_id[p] = t;
+        t_ce[0][p] = ce.x; t_ce[1][p] = ce.y; t_ce[2][p] = ce.z;
+        t_lo[0][p] = lo.x; t_lo[1][p] = lo.y; t_lo[2][p] = lo.z;
+        t_hi[0][p] = hi.x; t_hi[1][p] = hi.y; t_hi[2][p] = hi.z;
+        l_idx[p] = (uint16_t)p;
+        l_leaf[p] = 0;
+    }
+    SmallNode nd;
+    {
+        const float4 lo = s.nmin[root], hi = s.nmax[root], cl = s.cmin[root], ch = s.cmax[root];
+        nd.lo[0] = lo.x; nd.lo[1] = lo.y; nd.lo[2] = lo.z;
+        nd.hi[0] = hi.x; nd.hi[1] = hi.y; nd.hi[2] = hi.z;
+        nd.clo[0] = cl.x; nd.clo[1] = cl.y; nd.clo[2] = cl.z;
+        nd.chi[0] = ch.x; nd.chi[1] = ch.y; nd.chi[2] = ch.z;
+        nd.id = 0;
+        nd.depth = s.ndepth[root];
+        nd.a = 0;
+        nd.cnt = n;
+    }
+    int m = 1, nrec = 0, maxd = nd.depth, sp = 0;
+    bool have = true;
+    __syncthreads();
+
+    while (have) {
+        // ---- candidate planes: lane = axis * 16 + plane, the lexicographic order of the level loop's sweep ----------
+        const int ax = min(lane >> 4, 2), spl = lane & 15;
+        const bool cand = lane < 48 && spl < BB_BINS - 1;
+        float Llo[3] = {RT_INF, RT_INF, RT_INF}, Lhi[3] = {-RT_INF, -RT_INF, -RT_INF};
+        float Rlo[3] = {RT_INF, RT_INF, RT_INF}, Rhi[3] = {-RT_INF, -RT_INF, -RT_INF};
+        int lc = 0, rc = 0;
+        if (nd.cnt <= BS_DIRECT) {
+            if (lane < nd.cnt) {
+                const uint32_t slot = l_idx[nd.a + lane];
+                const uint32_t b0 = (uint32_t)bb_bin(t_ce[0][slot], nd.clo[0], nd.chi[0]);
+                const uint32_t b1 = (uint32_t)bb_bin(t_ce[1][slot], nd.clo[1], nd.chi[1]);
+                const uint32_t b2 = (uint32_t)bb_bin(t_ce[2][slot], nd.clo[2], nd.chi[2]);
+                l_tb[lane] = b0 | (b1 << 4) | (b2 << 8) | (slot << 12);
+            }
+            __syncthreads();
+            for (int k = 0; k < nd.cnt; k++) {
+                const uint32_t w = l_tb[k], slot = w >> 12;
+                const int bk = (int)((w >> (4 * ax)) & 15u);
+                const float lo0 = t_lo[0][slot], lo1 = t_lo[1][slot], lo2 = t_lo[2][slot];
+                const float hi0 = t_hi[0][slot], hi1 = t_hi[1][slot], hi2 = t_hi[2][slot];
+                if (bk <= spl) {
+                    Llo[0] = fminf(Llo[0], lo0); Llo[1] = fminf(Llo[1], lo1); Llo[2] = fminf(Llo[2], lo2);
+                    Lhi[0] = fmaxf(Lhi[0], hi0); Lhi[1] = fmaxf(Lhi[1], hi1); Lhi[2] = fmaxf(Lhi[2], hi2);
+                    lc++;
+                } else {
+                    Rlo[0] = fminf(Rlo[0], lo0); Rlo[1] = fminf(Rlo[1], lo1); Rlo[2] = fminf(Rlo[2], lo2);
+                    Rhi[0] = fmaxf(Rhi[0], hi0); Rhi[1] = fmaxf(Rhi[1], hi1); Rhi[2] = fmaxf(Rhi[2], hi2);
+                    rc++;
+                }
+            }
+        } else {
+            for (int k = lane; k < BB_NODE_WORDS; k += 64) {
+                const uint32_t w = (uint32_t)(k % BB_WORDS);
+                l_bins[k] = w == 0 ? 0u : (w <= 3 ? BB_KEY_POS_INF : BB_KEY_NEG_INF);
+            }
+            __syncthreads();
+            for (int p = lane; p < nd.cnt; p += 64) {
+                const uint32_t slot = l_idx[nd.a + p];
+                const float4 lo = make_float4(t_lo[0][slot], t_lo[1][slot], t_lo[2][slot], 0.0f);
+                const float4 hi = make_float4(t_hi[0][slot], t_hi[1][slot], t_hi[2][slot], 0.0f);
+#pragma unroll
+                for (int a2 = 0; a2 < 3; a2++)
+                    bb_accumulate(l_bins + (a2 * BB_BINS + bb_bin(t_ce[a2][slot], nd.clo[a2], nd.chi[a2])) * BB_WORDS, lo, hi);
+            }
+            __syncthreads();
+            for (int b = 0; b < BB_BINS; b++) {
+                const uint32_t* w = l_bins + (ax * BB_BINS + b) * BB_WORDS;
+                const int c = (int)w[0];
+                const float lo0 = bb_unkey(w[1]), lo1 = bb_unkey(w[2]), lo2 = bb_unkey(w[3]);
+                const float hi0 = bb_unkey(w[4]), hi1 = bb_unkey(w[5]), hi2 = bb_unkey(w[6]);
+                if (b <= spl) {
+                    Llo[0] = fminf(Llo[0], lo0); Llo[1] = fminf(Llo[1], lo1); Llo[2] = fminf(Llo[2], lo2);
+                    Lhi[0] = fmaxf(Lhi[0], hi0); Lhi[1] = fmaxf(Lhi[1], hi1); Lhi[2] = fmaxf(Lhi[2], hi2);
+                    lc += c;
+                } else {
+                    Rlo[0] = fminf(Rlo[0], lo0); Rlo[1] = fminf(Rlo[1], lo1); Rlo[2] = fminf(Rlo[2], lo2);
+                    Rhi[0] = fmaxf(Rhi[0], hi0); Rhi[1] = fmaxf(Rhi[1], hi1); Rhi[2] = fmaxf(Rhi[2], hi2);
+                    rc += c;
+                }
+            }
+        }
+        // same cost expressions as k_build_split; RT_INF = "not a candidate"
+        const float leaf_cost = (50.0f * (float)nd.cnt) * bb_area6(nd.lo, nd.hi);
+        float cost = RT_INF;
+        if (cand && lc > 0 && rc > 0 && nd.depth < BB_MAX_DEPTH) {
+            const float cst = (1.0f + (50.0f * (float)lc) * bb_area6(Llo, Lhi)) + (50.0f * (float)rc) * bb_area6(Rlo, Rhi);
+            if (cst < leaf_cost) cost = cst;
+        }
+        float mn = cost;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+        const unsigned long long win = __builtin_amdgcn_ballot_w64(cost == mn && cost < RT_INF);
+
+        SmallNode next[2];
+        bool act[2] = {false, false};
+        if (win == 0ull) {
+            // leaf: its positions already carry its id
+            if (lane == 0) bs_write_entry(sn, nd.id, nd.lo, nd.hi, -1, nd.a, nd.cnt, 0);
+        } else {
+            const int wl = __ffsll((long long)win) - 1;  // first (axis, plane) of minimum cost, as a strict '<' sweep keeps
+            const int best_axis = wl >> 4, best_bin = wl & 15;
+            const int nl = __shfl(lc, wl, 64);
+            float bl_lo[3], bl_hi[3], br_lo[3], br_hi[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                bl_lo[k] = __shfl(Llo[k], wl, 64);
+                bl_hi[k] = __shfl(Lhi[k], wl, 64);
+                br_lo[k] = __shfl(Rlo[k], wl, 64);
+                br_hi[k] = __shfl(Rhi[k], wl, 64);
+            }
+            const int c0 = m, rec = nrec;
+            m += 2;
+            nrec++;
+            maxd = max(maxd, nd.depth + 1);
+            if (lane == 0) bs_write_entry(sn, nd.id, nd.lo, nd.hi, c0, nd.a, nd.cnt, rec);
+            const float ca = bs_sel(best_axis, nd.clo[0], nd.clo[1], nd.clo[2]), cb2 = bs_sel(best_axis, nd.chi[0], nd.chi[1], nd.chi[2]);
+            const float plane = ca + (cb2 - ca) * ((float)(best_bin + 1) / (float)BB_BINS);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                SmallNode& ch = next[side];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    ch.lo[k] = side ? br_lo[k] : bl_lo[k];
+                    ch.hi[k] = side ? br_hi[k] : bl_hi[k];
+                    float ccl = nd.clo[k], cch = nd.chi[k];
+                    if (k == best_axis) {
+                        if (side) ccl = plane; else cch = plane;
+                    }
+                    ch.clo[k] = fmaxf(ccl, ch.lo[k]);  // centroid bounds may not exceed the child's own box
+                    ch.chi[k] = fminf(cch, ch.hi[k]);
+                }
+                ch.id = c0 + side;
+                ch.depth = nd.depth + 1;
+                ch.a = side ? nd.a + nl : nd.a;
+                ch.cnt = side ? nd.cnt - nl : nl;
+                act[side] = ch.cnt >= 2 && ch.depth < BB_MAX_DEPTH;
+                if (!act[side] && lane == side) bs_write_entry(sn, ch.id, ch.lo, ch.hi, -1, ch.a, ch.cnt, 0);
+            }
+            // ---- stable partition of the node's positions (at most BS_MAX / 64 chunks, all read before any write) ----
+            uint32_t slot_r[BS_MAX / 64];
+            bool right_r[BS_MAX / 64];
+#pragma unroll
+            for (int k = 0; k < BS_MAX / 64; k++) {
+                const int p = k * 64 + lane;
+                slot_r[k] = 0;
+                right_r[k] = false;
+                if (p < nd.cnt) {
+                    slot_r[k] = l_idx[nd.a + p];
+                    right_r[k] = bb_bin(t_ce[best_axis][slot_r[k]], ca, cb2) > best_bin;
+                }
+            }
+            __syncthreads();
+            int lbase = 0, rbase = 0;
+#pragma unroll
+            for (int k = 0; k < BS_MAX / 64; k++) {
+                const int p = k * 64 + lane;
+                const bool in = p < nd.cnt;
+                const unsigned long long bl = __builtin_amdgcn_ballot_w64(in && !right_r[k]);
+                const unsigned long long br = __builtin_amdgcn_ballot_w64(in && right_r[k]);
+                const unsigned long long mine = right_r[k] ? br : bl;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                if (in) {
+                    const int dest = nd.a + (right_r[k] ? nl + rbase + rank : lbase + rank);
+                    l_idx[dest] = (uint16_t)slot_r[k];
+                    l_leaf[dest] = (uint16_t)(c0 + (right_r[k] ? 1 : 0));
+                }
+                lbase += (int)__builtin_popcountll(bl);
+                rbase += (int)__builtin_popcountll(br);
+            }
+            __syncthreads();
+        }
+        // ---- next node: left child, else right child, else the most recent pending sibling ----------------------------
+        if (act[0]) {
+            if (act[1] && sp < BS_STACK) {
+                if (lane == 0) {
+                    float* e = l_stk[sp];
+                    for (int k = 0; k < 3; k++) {
+                        e[k] = next[1].lo[k]; e[3 + k] = next[1].hi[k]; e[6 + k] = next[1].clo[k]; e[9 + k] = next[1].chi[k];
+                    }
+                    e[12] = rt_u2f((uint32_t)next[1].id); e[13] = rt_u2f((uint32_t)next[1].depth);
+                    e[14] = rt_u2f((uint32_t)next[1].a); e[15] = rt_u2f((uint32_t)next[1].cnt);
+                }
+                sp++;
+            } else if (act[1]) {
+                if (lane == 0) bs_write_entry(sn, next[1].id, next[1].lo, next[1].hi, -1, next[1].a, next[1].cnt, 0);  // cannot happen
+            }
+            nd = next[0];
+        } else if (act[1]) {
+            nd = next[1];
+        } else if (sp > 0) {
+            sp--;
+            __syncthreads();
+            const float* e = l_stk[sp];
+            for (int k = 0; k < 3; k++) {
+                nd.lo[k] = e[k]; nd.hi[k] = e[3 + k]; nd.clo[k] = e[6 + k]; nd.chi[k] = e[9 + k];
+            }
+            nd.id = (int)rt_f2u(e[12]); nd.depth = (int)rt_f2u(e[13]); nd.a = (int)rt_f2u(e[14]); nd.cnt = (int)rt_f2u(e[15]);
+            __syncthreads();
+        } else {
+            have = false;
+        }
+    }
+
+    // ---- ids for the new nodes and records, then copy the subtree out --------------------------------------------------
+    if (lane == 0) {
+        l_alloc[0] = m > 1 ? atomicAdd(&s.counters[0], m - 1) : 0;
+        l_alloc[1] = nrec > 0 ? atomicAdd(&s.counters[1], nrec) : 0;
+        if (m > 1) atomicMax(&s.counters[3], maxd);
+    }
+    __threadfence();
+    __syncthreads();
+    const int base_node = l_alloc[0], base_rec = l_alloc[1];
+    for (int j = lane; j < m; j += 64) {
+        const float4 e0 = sn[2 * j], e1 = sn[2 * j + 1];
+        const int child = (int)rt_f2u(e0.w);
+        const uint32_t pk = rt_f2u(e1.w);
+        const int g = j == 0 ? root : base_node + j - 1;
+        s.nmin[g] = make_float4(e0.x, e0.y, e0.z, 0.0f);
+        s.nmax[g] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+        s.nstart[g] = start + (int)(pk & 0xfffu);
+        s.ncount[g] = (int)((pk >> 12) & 0xfffu);
+        s.nchild[g] = child < 0 ? -1 : base_node + child - 1;
+        s.nrec[g] = child < 0 ? -1 : base_rec + (int)(pk >> 24);
+    }
+    for (int p = lane; p < n; p += 64) {
+        const int j = (int)l_leaf[p];
+        s.order[cur][start + p] = t_id[l_idx[p]];
+        s.node_of[cur][start + p] = j == 0 ? root : base_node + j - 1;
+    }
+}
+
 // ---- emission ---------------------------------------------------------------------------------------------------
-// reference-format node rows (for download) and the 64-byte inner-node records of the render kernels
-__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_nodes(BuildState s, int num_nodes, float* ref_nodes, float4* recs) {
+// the 64-byte inner-node records of the render kernels
+__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_recs(BuildState s, int num_nodes, float4* recs) {
     int i = blockIdx.x * BB_BLOCK + threadIdx.x;
     if (i >= num_nodes) return;
-    float4 lo = s.nmin[i], hi = s.nmax[i];
-    int c0 = s.nchild[i];
-    float* r = ref_nodes + (size_t)12 * i;
-    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = 0.0f;
-    r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = 0.0f;
-    r[11] = 0.0f;
-    if (c0 < 0) {
-        r[8] = 1.0f;
-        r[9] = (float)s.nstart[i];
-        r[10] = (float)(s.nstart[i] + s.ncount[i] - 1);
-        return;
-    }
-    r[8] = 0.0f;
-    r[9] = (float)c0;
-    r[10] = (float)(c0 + 1);
+    const int c0 = s.nchild[i];
+    if (c0 < 0) return;
     int ref[2];
     float4 blo[2], bhi[2];
     for (int k = 0; k < 2; k++) {
@@ -381,28 +772,57 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_nodes(BuildState s, int
     q[3] = make_float4(rt_u2f((uint32_t)ref[0]), rt_u2f((uint32_t)ref[1]), 0.0f, 0.0f);
 }
 
-// triangle records, the reference's vertex arrays in leaf order, colours gathered by face
+// triangle records in leaf order and the shade records (normal as shaders/normals.glsl:13-19 computes it, colour)
 __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int cur, int n, const float* verts,
                                                               const uint32_t* faces, const float4* face_colours, float4* tris,
-                                                              float4* v0, float4* v1, float4* v2, float4* colours) {
+                                                              float4* shade) {
     int k = blockIdx.x * BB_BLOCK + threadIdx.x;
     if (k >= n) return;
     uint32_t t = s.order[cur][k];
     int node = s.node_of[cur][k];
     uint32_t ia = faces[3 * t], ib = faces[3 * t + 1], ic = faces[3 * t + 2];
-    float4 a = make_float4(verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2], 0.0f);
-    float4 b = make_float4(verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2], 0.0f);
-    float4 c = make_float4(verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2], 0.0f);
-    v0[k] = a;
-    v1[k] = b;
-    v2[k] = c;
-    colours[k] = face_colours[t];
+    const rt_vec3 a = rt_v3(verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]);
+    const rt_vec3 b = rt_v3(verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]);
+    const rt_vec3 c = rt_v3(verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]);
     bool last = k == s.nstart[node] + s.ncount[node] - 1;
     float4* q = tris + (size_t)k * 4;
     q[0] = make_float4(a.x, a.y, a.z, rt_u2f(last ? 1u : 0u));
     q[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, rt_u2f((uint32_t)k));
     q[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0f);
     q[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const rt_vec3 nrm = rt_normalize(rt_cross(rt_sub(a, b), rt_sub(a, c)));
+    const float4 col = face_colours[t];
+    shade[2 * (size_t)k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+    shade[2 * (size_t)k + 1] = make_float4(col.x, col.y, col.z, 0.0f);
+}
+
+// the same tree in the reference's buffer layout (scene-loader.h:7-15), produced on demand for downloads
+__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_ref_nodes(BuildState s, int num_nodes, float* ref_nodes) {
+    int i = blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (i >= num_nodes) return;
+    float4 lo = s.nmin[i], hi = s.nmax[i];
+    int c0 = s.nchild[i];
+    float* r = ref_nodes + (size_t)12 * i;
+    r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = 0.0f;
+    r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = 0.0f;
+    r[8] = c0 < 0 ? 1.0f : 0.0f;
+    r[9] = c0 < 0 ? (float)s.nstart[i] : (float)c0;
+    r[10] = c0 < 0 ? (float)(s.nstart[i] + s.ncount[i] - 1) : (float)(c0 + 1);
+    r[11] = 0.0f;
+}
+
+__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_ref_tris(BuildState s, int cur, int n, const float* verts,
+                                                                  const uint32_t* faces, const float4* face_colours, float4* v0,
+                                                                  float4* v1, float4* v2, float4* colours, uint32_t* src) {
+    int k = blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    uint32_t t = s.order[cur][k];
+    uint32_t ia = faces[3 * t], ib = faces[3 * t + 1], ic = faces[3 * t + 2];
+    v0[k] = make_float4(verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2], 0.0f);
+    v1[k] = make_float4(verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2], 0.0f);
+    v2[k] = make_float4(verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2], 0.0f);
+    colours[k] = face_colours[t];
+    src[k] = t;
 }
 
 #endif  // RT_BUILD_H

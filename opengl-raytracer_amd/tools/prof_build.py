@@ -21,7 +21,11 @@ def main():
     ap.add_argument("--scene", default="grid")
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--render", type=int, default=0)
+    ap.add_argument("--rebuild", type=int, default=0, help="rebuilds from perturbed device-resident vertices")
+    ap.add_argument("--gen", default=None, help="builder generation (sets RT_BUILD_GEN)")
     a = ap.parse_args()
+    if a.gen:
+        os.environ["RT_BUILD_GEN"] = a.gen
     pkg = entry.load_package()
     fx = os.path.join(ROOT, "fixtures")
     if a.scene == "grid":
@@ -41,6 +45,13 @@ def main():
         n, t, ms = C.c_int32(), C.c_int32(), C.c_float()
         ctx.lib.rt_get_built_scene(ctx.ctx, C.byref(n), C.byref(t), None, None, None, None, None, None, C.byref(ms))
         print(f"build {r}: {t.value} triangles -> {n.value} nodes: device {ms.value:.2f} ms, call {wall * 1e3:.1f} ms (incl. validation + upload)")
+    if a.rebuild:
+        for r in range(a.rebuild):
+            d_w = pkg.DeviceBuffer.from_array((v + 0.01 * np.sin(v * 3.0 + float(r))).astype(np.float32))
+            t0 = time.perf_counter()
+            _, ms = ctx.rebuild_scene_device(d_w.ptr)
+            print(f"rebuild {r}: device {ms:.2f} ms, call {(time.perf_counter() - t0) * 1e3:.2f} ms")
+            d_w.free()
     if a.render:
         ctx.num_tris = f.shape[0]
         cam = pkg.make_camera(pos=pos)

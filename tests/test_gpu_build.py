@@ -118,6 +118,90 @@ def test_device_build_same_primary_image_as_reference_builder(pkg, oracle, scene
     ctx.close()
 
 
+def _canonical(scene):
+    """Order-independent description of a built tree: the sorted node boxes with their kind, and for every face the
+    box and size of the leaf it ended up in.  Two builds of the same tree agree on it whatever ids their nodes got."""
+    nodes = scene.nodes
+    rows = np.ascontiguousarray(nodes[:, [0, 1, 2, 4, 5, 6, 8]] + 0.0)       # + 0.0 folds -0 into +0
+    rows = rows[np.lexsort(rows.T[::-1])]
+    leaf = np.nonzero(nodes[:, 8] == 1.0)[0]
+    a, b = nodes[leaf, 9].astype(np.int64), nodes[leaf, 10].astype(np.int64)
+    order = np.argsort(a)
+    owner = np.repeat(leaf[order], (b - a + 1)[order])
+    per_face = np.empty((scene.num_tris, 7), dtype=np.float32)
+    per_face[scene.tri_src] = np.concatenate([nodes[owner][:, [0, 1, 2, 4, 5, 6]] + 0.0,
+                                              np.repeat((b - a + 1)[order], (b - a + 1)[order])[:, None].astype(np.float32)], axis=1)
+    return rows, per_face
+
+
+@pytest.mark.parametrize("name", ["teapot", "dragon80k", "soup"])
+def test_small_subtree_kernel_builds_the_same_tree_as_the_level_loop(pkg, name):
+    """The second-generation builder (segment-walking level loop + one wavefront per small subtree) must produce
+    exactly the tree of the plain level-synchronous builder: same boxes, same leaves."""
+    v, f = _soup() if name == "soup" else _read_obj(pkg, name)
+    col = pkg.make_colours(2, f.shape[0])
+    built = {}
+    for gen in ("1", "2"):
+        os.environ["RT_BUILD_GEN"] = gen
+        try:
+            ctx = pkg.RenderContext(0)
+        finally:
+            del os.environ["RT_BUILD_GEN"]
+        built[gen], ms = ctx.build_scene_device(v, f, col)
+        print(f"\n[gpu build] {name} generation {gen}: {built[gen].num_nodes} nodes, {ms:.2f} ms", flush=True)
+        ctx.close()
+    assert built["1"].num_nodes == built["2"].num_nodes
+    rows1, faces1 = _canonical(built["1"])
+    rows2, faces2 = _canonical(built["2"])
+    assert np.array_equal(rows1, rows2)
+    assert np.array_equal(faces1, faces2)
+
+
+def test_rebuild_from_device_vertices(pkg, oracle):
+    """rt_rebuild_scene_device: same topology, new vertex positions from a device pointer; per-tree parity with the
+    oracle, and the same tree as a fresh build from host memory."""
+    v, f = _read_obj(pkg, "dragon80k")
+    col = pkg.make_colours(4, f.shape[0])
+    ctx = pkg.RenderContext(0)
+    with pytest.raises(RuntimeError):
+        ctx.rebuild_scene_device(0)
+    d_any = pkg.DeviceBuffer.from_array(v)
+    with pytest.raises(RuntimeError):
+        ctx.rebuild_scene_device(d_any.ptr)                                # nothing built yet
+    d_any.free()
+    ctx.build_scene_device(v, f, col, download=False)
+    cam = pkg.make_camera(pos=CAMS["dragon80k"])
+    rng = np.random.RandomState(5)
+    for step in range(3):
+        v2 = (v + rng.normal(0.0, 0.02, v.shape)).astype(np.float32)
+        d_v = pkg.DeviceBuffer.from_array(v2)
+        built, ms = ctx.rebuild_scene_device(d_v.ptr, download=True)
+        d_v.free()                                                         # the context keeps its own copy
+        _validate_tree(built, v2, f)
+        assert np.array_equal(built.colours, col[built.tri_src])
+        p = pkg.make_params(480, 270, frames=2, flags=pkg.RT_FLAG_COUNTERS)
+        ctx.reset_counters()
+        got = ctx.render(cam, p)
+        cnt = ctx.counters()
+        want, cnt_o = oracle.render(built, cam, p)
+        assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+        assert np.array_equal(bits(ctx.get_normals()), bits(oracle.normals(built)))
+        print(f"\n[gpu build] rebuild {step}: {built.num_nodes} nodes, {ms:.2f} ms", flush=True)
+    fresh_ctx = pkg.RenderContext(0)
+    fresh, _ = fresh_ctx.build_scene_device(v2, f, col)
+    ra, fa = _canonical(built)
+    rb, fb = _canonical(fresh)
+    assert np.array_equal(ra, rb) and np.array_equal(fa, fb)
+    fresh_ctx.close()
+    # an uploaded scene replaces the built one: nothing to rebuild from
+    ctx.upload_scene(fresh)
+    d_v = pkg.DeviceBuffer.from_array(v2)
+    with pytest.raises(RuntimeError):
+        ctx.rebuild_scene_device(d_v.ptr)
+    d_v.free()
+    ctx.close()
+
+
 def test_device_build_rejects_bad_input(pkg):
     ctx = pkg.RenderContext(0)
     v = np.zeros((3, 3), dtype=np.float32)
@@ -147,7 +231,13 @@ def test_device_build_big_scene_and_animation(pkg, oracle):
     rng = np.random.RandomState(0)
     for step in range(2):
         t0 = time.time()
-        built, ms = ctx.build_scene_device(v, f, col)
+        if step == 0:
+            built, ms = ctx.build_scene_device(v, f, col)
+        else:
+            d_v = pkg.DeviceBuffer.from_array(v)
+            built, ms = ctx.rebuild_scene_device(d_v.ptr, download=True)
+            d_v.free()
+            _validate_tree(built, v, f)
         wall = time.time() - t0
         print(f"\n[gpu build] step {step}: {built.num_tris} triangles -> {built.num_nodes} nodes, device build {ms:.1f} ms "
               f"(call incl. upload + download of the tree {wall:.1f} s)", flush=True)
