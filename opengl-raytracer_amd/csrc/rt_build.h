@@ -160,6 +160,39 @@ __device__ __forceinline__ void bb_accumulate(uint32_t* b, float4 lo, float4 hi)
     atomicMax(&b[6], bb_key(hi.z));
 }
 
+// Wave-wide unsigned min / max with DPP; all 64 lanes must be active; the result is valid in lane 63.
+#define BB_DPP_STEP(op, x, ctrl, rmask) x = op(x, (uint32_t)__builtin_amdgcn_update_dpp((int)(x), (int)(x), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ uint32_t bb_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t bb_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t bb_wave_min(uint32_t x) {
+    BB_DPP_STEP(bb_umin, x, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+    BB_DPP_STEP(bb_umin, x, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+    BB_DPP_STEP(bb_umin, x, 0x141, 0xf);  // row_half_mirror
+    BB_DPP_STEP(bb_umin, x, 0x140, 0xf);  // row_mirror: every lane holds its row's result
+    BB_DPP_STEP(bb_umin, x, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    BB_DPP_STEP(bb_umin, x, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ uint32_t bb_wave_max(uint32_t x) {
+    BB_DPP_STEP(bb_umax, x, 0xB1, 0xf);
+    BB_DPP_STEP(bb_umax, x, 0x4E, 0xf);
+    BB_DPP_STEP(bb_umax, x, 0x141, 0xf);
+    BB_DPP_STEP(bb_umax, x, 0x140, 0xf);
+    BB_DPP_STEP(bb_umax, x, 0x142, 0xa);
+    BB_DPP_STEP(bb_umax, x, 0x143, 0xc);
+    return x;
+}
+
+__device__ __forceinline__ void bb_accumulate_n(uint32_t* b, uint32_t n, float4 lo, float4 hi) {
+    atomicAdd(&b[0], n);
+    atomicMin(&b[1], bb_key(lo.x));
+    atomicMin(&b[2], bb_key(lo.y));
+    atomicMin(&b[3], bb_key(lo.z));
+    atomicMax(&b[4], bb_key(hi.x));
+    atomicMax(&b[5], bb_key(hi.y));
+    atomicMax(&b[6], bb_key(hi.z));
+}
+
 __global__ __launch_bounds__(BB_BLOCK) void k_build_bin(BuildState s, int cur, int n) {
     __shared__ uint32_t l_bins[BB_NODE_WORDS];
     __shared__ int l_node, l_uniform;
@@ -381,12 +414,56 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_bin2(BuildState s, int cur, 
             }
             __syncthreads();
             const float4 c0 = s.cmin[node], c1 = s.cmax[node];
-            for (int i = pos + (int)threadIdx.x; i < end; i += BB_BLOCK) {
-                const uint32_t t = s.order[cur][i];
-                const float4 ce = s.tcen[t], lo = s.tmin[t], hi = s.tmax[t];
-                const int b[3] = {bb_bin(ce.x, c0.x, c1.x), bb_bin(ce.y, c0.y, c1.y), bb_bin(ce.z, c0.z, c1.z)};
+            // Neighbouring triangles of a mesh mostly fall into the same bin, which would serialise per-lane LDS atomics
+            // 64-fold.  Per axis the wavefront therefore peels off one bin at a time: lanes of the leader's bin are
+            // reduced with DPP and one lane issues the seven atomics.  Scattered bins (few lanes each) take the plain
+            // per-lane path.
+            const int lane = threadIdx.x & 63;
+            for (int base = pos; base < end; base += BB_BLOCK) {
+                const int i = base + (int)threadIdx.x;
+                const bool in = i < end;
+                uint32_t klo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, khi[3] = {0u, 0u, 0u};
+                int b[3] = {0, 0, 0};
+                if (in) {
+                    const uint32_t t = s.order[cur][i];
+                    const float4 ce = s.tcen[t], lo = s.tmin[t], hi = s.tmax[t];
+                    b[0] = bb_bin(ce.x, c0.x, c1.x); b[1] = bb_bin(ce.y, c0.y, c1.y); b[2] = bb_bin(ce.z, c0.z, c1.z);
+                    klo[0] = bb_key(lo.x); klo[1] = bb_key(lo.y); klo[2] = bb_key(lo.z);
+                    khi[0] = bb_key(hi.x); khi[1] = bb_key(hi.y); khi[2] = bb_key(hi.z);
+                }
 #pragma unroll
-                for (int ax = 0; ax < 3; ax++) bb_accumulate(l_bins + (ax * BB_BINS + b[ax]) * BB_WORDS, lo, hi);
+                for (int ax = 0; ax < 3; ax++) {
+                    unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const int lb = __builtin_amdgcn_readlane(b[ax], leader);
+                        const bool mine = in && b[ax] == lb;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine) & todo;
+                        const int members = (int)__builtin_popcountll(mask);
+                        if (members < 8) {
+                            // scattered: everybody left adds its own triangle
+                            if ((todo >> lane) & 1ull) {
+                                uint32_t* w = l_bins + (ax * BB_BINS + b[ax]) * BB_WORDS;
+                                atomicAdd(&w[0], 1u);
+                                atomicMin(&w[1], klo[0]); atomicMin(&w[2], klo[1]); atomicMin(&w[3], klo[2]);
+                                atomicMax(&w[4], khi[0]); atomicMax(&w[5], khi[1]); atomicMax(&w[6], khi[2]);
+                            }
+                            break;
+                        }
+                        const bool sel = (mask >> lane) & 1ull;
+                        const uint32_t m0 = bb_wave_min(sel ? klo[0] : 0xffffffffu), m1 = bb_wave_min(sel ? klo[1] : 0xffffffffu),
+                                       m2 = bb_wave_min(sel ? klo[2] : 0xffffffffu);
+                        const uint32_t x0 = bb_wave_max(sel ? khi[0] : 0u), x1 = bb_wave_max(sel ? khi[1] : 0u),
+                                       x2 = bb_wave_max(sel ? khi[2] : 0u);
+                        if (lane == 63) {  // the DPP reductions end in the last lane
+                            uint32_t* w = l_bins + (ax * BB_BINS + lb) * BB_WORDS;
+                            atomicAdd(&w[0], (uint32_t)members);
+                            atomicMin(&w[1], m0); atomicMin(&w[2], m1); atomicMin(&w[3], m2);
+                            atomicMax(&w[4], x0); atomicMax(&w[5], x1); atomicMax(&w[6], x2);
+                        }
+                        todo &= ~mask;
+                    }
+                }
             }
             __syncthreads();
             uint32_t* g = s.bins + (size_t)slot * BB_NODE_WORDS;
@@ -485,11 +562,48 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_partition2(BuildState s, int
 
 __device__ __forceinline__ float bs_sel(int ax, float x, float y, float z) { return ax == 0 ? x : (ax == 1 ? y : z); }
 
+__device__ __forceinline__ float bs_bcast(float x, int src_lane) {  // src_lane must be wave-uniform
+    return rt_u2f((uint32_t)__builtin_amdgcn_readlane((int)rt_f2u(x), src_lane));
+}
+// minimum over each row of 16 lanes (all lanes active), left in every lane of the row
+__device__ __forceinline__ float bs_row_min(float x) {
+#define BS_DPP_MIN(ctrl)                                                                                      \
+    x = fminf(x, rt_u2f((uint32_t)__builtin_amdgcn_update_dpp((int)rt_f2u(x), (int)rt_f2u(x), ctrl, 0xf, 0xf, false)))
+    BS_DPP_MIN(0xB1);   // quad_perm [1,0,3,2]
+    BS_DPP_MIN(0x4E);   // quad_perm [2,3,0,1]
+    BS_DPP_MIN(0x141);  // row_half_mirror
+    BS_DPP_MIN(0x140);  // row_mirror
+#undef BS_DPP_MIN
+    return x;
+}
+
+// Orders the LDS traffic of a one-wavefront workgroup: its DS instructions execute in program order, so a compiler
+// fence is all that is needed -- __syncthreads() would also wait for the outstanding global stores (microseconds).
+__device__ __forceinline__ void bs_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct SmallNode {  // wave-uniform description of the node being worked on
     float lo[3], hi[3];    // box
     float clo[3], chi[3];  // centroid bounds (the binning interval)
     int id, depth, a, cnt; // local id, depth, first position (relative) and triangle count
 };
+
+// tells the compiler that the node description is the same in every lane (it is: it comes from uniform addresses)
+__device__ __forceinline__ void bs_make_uniform(SmallNode& n) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        n.lo[k] = rt_u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)rt_f2u(n.lo[k])));
+        n.hi[k] = rt_u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)rt_f2u(n.hi[k])));
+        n.clo[k] = rt_u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)rt_f2u(n.clo[k])));
+        n.chi[k] = rt_u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)rt_f2u(n.chi[k])));
+    }
+    n.id = __builtin_amdgcn_readfirstlane(n.id);
+    n.depth = __builtin_amdgcn_readfirstlane(n.depth);
+    n.a = __builtin_amdgcn_readfirstlane(n.a);
+    n.cnt = __builtin_amdgcn_readfirstlane(n.cnt);
+}
 
 __device__ __forceinline__ void bs_write_entry(float4* sn, int id, const float* lo, const float* hi, int child, int a, int cnt, int rec) {
     sn[2 * id] = make_float4(lo[0], lo[1], lo[2], rt_u2f((uint32_t)child));
@@ -502,7 +616,6 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
     __shared__ uint16_t l_idx[BS_MAX];                                      // position -> slot
     __shared__ uint16_t l_leaf[BS_MAX];                                     // position -> local id of the node it ends in
     __shared__ uint32_t l_bins[BB_NODE_WORDS];
-    __shared__ uint32_t l_tb[BS_DIRECT];
     __shared__ float l_stk[BS_STACK][16];
     __shared__ int l_alloc[2];
     const int lane = threadIdx.x;
@@ -533,32 +646,41 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
         nd.depth = s.ndepth[root];
         nd.a = 0;
         nd.cnt = n;
+        bs_make_uniform(nd);
     }
     int m = 1, nrec = 0, maxd = nd.depth, sp = 0;
     bool have = true;
-    __syncthreads();
+    bs_sync();
 
     while (have) {
+        const int cnt = nd.cnt;
+        // ---- this lane's triangle of the node's first 64 positions, kept in registers for the whole visit -------------
+        const bool in0 = lane < cnt;
+        uint32_t slot0 = 0u;
+        float q_lo[3] = {RT_INF, RT_INF, RT_INF}, q_hi[3] = {-RT_INF, -RT_INF, -RT_INF};
+        int q_b[3] = {0, 0, 0};
+        if (in0) {
+            slot0 = l_idx[nd.a + lane];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                q_lo[k] = t_lo[k][slot0];
+                q_hi[k] = t_hi[k][slot0];
+                q_b[k] = bb_bin(t_ce[k][slot0], nd.clo[k], nd.chi[k]);
+            }
+        }
         // ---- candidate planes: lane = axis * 16 + plane, the lexicographic order of the level loop's sweep ----------
         const int ax = min(lane >> 4, 2), spl = lane & 15;
         const bool cand = lane < 48 && spl < BB_BINS - 1;
         float Llo[3] = {RT_INF, RT_INF, RT_INF}, Lhi[3] = {-RT_INF, -RT_INF, -RT_INF};
         float Rlo[3] = {RT_INF, RT_INF, RT_INF}, Rhi[3] = {-RT_INF, -RT_INF, -RT_INF};
         int lc = 0, rc = 0;
-        if (nd.cnt <= BS_DIRECT) {
-            if (lane < nd.cnt) {
-                const uint32_t slot = l_idx[nd.a + lane];
-                const uint32_t b0 = (uint32_t)bb_bin(t_ce[0][slot], nd.clo[0], nd.chi[0]);
-                const uint32_t b1 = (uint32_t)bb_bin(t_ce[1][slot], nd.clo[1], nd.chi[1]);
-                const uint32_t b2 = (uint32_t)bb_bin(t_ce[2][slot], nd.clo[2], nd.chi[2]);
-                l_tb[lane] = b0 | (b1 << 4) | (b2 << 8) | (slot << 12);
-            }
-            __syncthreads();
-            for (int k = 0; k < nd.cnt; k++) {
-                const uint32_t w = l_tb[k], slot = w >> 12;
-                const int bk = (int)((w >> (4 * ax)) & 15u);
-                const float lo0 = t_lo[0][slot], lo1 = t_lo[1][slot], lo2 = t_lo[2][slot];
-                const float hi0 = t_hi[0][slot], hi1 = t_hi[1][slot], hi2 = t_hi[2][slot];
+        if (cnt <= BS_DIRECT) {
+            // few triangles: every candidate lane unions them directly, operands broadcast from the owning lanes
+            const int pk = q_b[0] | (q_b[1] << 4) | (q_b[2] << 8);
+            for (int k = 0; k < cnt; k++) {
+                const int bk = (__builtin_amdgcn_readlane(pk, k) >> (4 * ax)) & 15;
+                const float lo0 = bs_bcast(q_lo[0], k), lo1 = bs_bcast(q_lo[1], k), lo2 = bs_bcast(q_lo[2], k);
+                const float hi0 = bs_bcast(q_hi[0], k), hi1 = bs_bcast(q_hi[1], k), hi2 = bs_bcast(q_hi[2], k);
                 if (bk <= spl) {
                     Llo[0] = fminf(Llo[0], lo0); Llo[1] = fminf(Llo[1], lo1); Llo[2] = fminf(Llo[2], lo2);
                     Lhi[0] = fmaxf(Lhi[0], hi0); Lhi[1] = fmaxf(Lhi[1], hi1); Lhi[2] = fmaxf(Lhi[2], hi2);
@@ -574,8 +696,13 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
                 const uint32_t w = (uint32_t)(k % BB_WORDS);
                 l_bins[k] = w == 0 ? 0u : (w <= 3 ? BB_KEY_POS_INF : BB_KEY_NEG_INF);
             }
-            __syncthreads();
-            for (int p = lane; p < nd.cnt; p += 64) {
+            bs_sync();
+            if (in0) {
+                const float4 lo = make_float4(q_lo[0], q_lo[1], q_lo[2], 0.0f), hi = make_float4(q_hi[0], q_hi[1], q_hi[2], 0.0f);
+#pragma unroll
+                for (int a2 = 0; a2 < 3; a2++) bb_accumulate(l_bins + (a2 * BB_BINS + q_b[a2]) * BB_WORDS, lo, hi);
+            }
+            for (int p = 64 + lane; p < cnt; p += 64) {
                 const uint32_t slot = l_idx[nd.a + p];
                 const float4 lo = make_float4(t_lo[0][slot], t_lo[1][slot], t_lo[2][slot], 0.0f);
                 const float4 hi = make_float4(t_hi[0][slot], t_hi[1][slot], t_hi[2][slot], 0.0f);
@@ -583,7 +710,7 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
                 for (int a2 = 0; a2 < 3; a2++)
                     bb_accumulate(l_bins + (a2 * BB_BINS + bb_bin(t_ce[a2][slot], nd.clo[a2], nd.chi[a2])) * BB_WORDS, lo, hi);
             }
-            __syncthreads();
+            bs_sync();
             for (int b = 0; b < BB_BINS; b++) {
                 const uint32_t* w = l_bins + (ax * BB_BINS + b) * BB_WORDS;
                 const int c = (int)w[0];
@@ -601,39 +728,38 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
             }
         }
         // same cost expressions as k_build_split; RT_INF = "not a candidate"
-        const float leaf_cost = (50.0f * (float)nd.cnt) * bb_area6(nd.lo, nd.hi);
+        const float leaf_cost = (50.0f * (float)cnt) * bb_area6(nd.lo, nd.hi);
         float cost = RT_INF;
         if (cand && lc > 0 && rc > 0 && nd.depth < BB_MAX_DEPTH) {
             const float cst = (1.0f + (50.0f * (float)lc) * bb_area6(Llo, Lhi)) + (50.0f * (float)rc) * bb_area6(Rlo, Rhi);
             if (cst < leaf_cost) cost = cst;
         }
-        float mn = cost;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+        const float rmn = bs_row_min(cost);  // rows 0..2 hold the three axes
+        const float mn = fminf(fminf(bs_bcast(rmn, 0), bs_bcast(rmn, 16)), bs_bcast(rmn, 32));
         const unsigned long long win = __builtin_amdgcn_ballot_w64(cost == mn && cost < RT_INF);
 
         SmallNode next[2];
         bool act[2] = {false, false};
         if (win == 0ull) {
             // leaf: its positions already carry its id
-            if (lane == 0) bs_write_entry(sn, nd.id, nd.lo, nd.hi, -1, nd.a, nd.cnt, 0);
+            if (lane == 0) bs_write_entry(sn, nd.id, nd.lo, nd.hi, -1, nd.a, cnt, 0);
         } else {
             const int wl = __ffsll((long long)win) - 1;  // first (axis, plane) of minimum cost, as a strict '<' sweep keeps
             const int best_axis = wl >> 4, best_bin = wl & 15;
-            const int nl = __shfl(lc, wl, 64);
+            const int nl = __builtin_amdgcn_readlane(lc, wl);
             float bl_lo[3], bl_hi[3], br_lo[3], br_hi[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                bl_lo[k] = __shfl(Llo[k], wl, 64);
-                bl_hi[k] = __shfl(Lhi[k], wl, 64);
-                br_lo[k] = __shfl(Rlo[k], wl, 64);
-                br_hi[k] = __shfl(Rhi[k], wl, 64);
+                bl_lo[k] = bs_bcast(Llo[k], wl);
+                bl_hi[k] = bs_bcast(Lhi[k], wl);
+                br_lo[k] = bs_bcast(Rlo[k], wl);
+                br_hi[k] = bs_bcast(Rhi[k], wl);
             }
             const int c0 = m, rec = nrec;
             m += 2;
             nrec++;
             maxd = max(maxd, nd.depth + 1);
-            if (lane == 0) bs_write_entry(sn, nd.id, nd.lo, nd.hi, c0, nd.a, nd.cnt, rec);
+            if (lane == 0) bs_write_entry(sn, nd.id, nd.lo, nd.hi, c0, nd.a, cnt, rec);
             const float ca = bs_sel(best_axis, nd.clo[0], nd.clo[1], nd.clo[2]), cb2 = bs_sel(best_axis, nd.chi[0], nd.chi[1], nd.chi[2]);
             const float plane = ca + (cb2 - ca) * ((float)(best_bin + 1) / (float)BB_BINS);
 #pragma unroll
@@ -653,29 +779,34 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
                 ch.id = c0 + side;
                 ch.depth = nd.depth + 1;
                 ch.a = side ? nd.a + nl : nd.a;
-                ch.cnt = side ? nd.cnt - nl : nl;
+                ch.cnt = side ? cnt - nl : nl;
                 act[side] = ch.cnt >= 2 && ch.depth < BB_MAX_DEPTH;
                 if (!act[side] && lane == side) bs_write_entry(sn, ch.id, ch.lo, ch.hi, -1, ch.a, ch.cnt, 0);
             }
             // ---- stable partition of the node's positions (at most BS_MAX / 64 chunks, all read before any write) ----
             uint32_t slot_r[BS_MAX / 64];
             bool right_r[BS_MAX / 64];
+            slot_r[0] = slot0;
+            right_r[0] = in0 && (best_axis == 0 ? q_b[0] : (best_axis == 1 ? q_b[1] : q_b[2])) > best_bin;
+            if (cnt > 64) {
 #pragma unroll
-            for (int k = 0; k < BS_MAX / 64; k++) {
-                const int p = k * 64 + lane;
-                slot_r[k] = 0;
-                right_r[k] = false;
-                if (p < nd.cnt) {
-                    slot_r[k] = l_idx[nd.a + p];
-                    right_r[k] = bb_bin(t_ce[best_axis][slot_r[k]], ca, cb2) > best_bin;
+                for (int k = 1; k < BS_MAX / 64; k++) {
+                    const int p = k * 64 + lane;
+                    slot_r[k] = 0;
+                    right_r[k] = false;
+                    if (p < cnt) {
+                        slot_r[k] = l_idx[nd.a + p];
+                        right_r[k] = bb_bin(t_ce[best_axis][slot_r[k]], ca, cb2) > best_bin;
+                    }
                 }
+                bs_sync();
             }
-            __syncthreads();
             int lbase = 0, rbase = 0;
 #pragma unroll
             for (int k = 0; k < BS_MAX / 64; k++) {
+                if (k > 0 && cnt <= 64 * k) break;
                 const int p = k * 64 + lane;
-                const bool in = p < nd.cnt;
+                const bool in = p < cnt;
                 const unsigned long long bl = __builtin_amdgcn_ballot_w64(in && !right_r[k]);
                 const unsigned long long br = __builtin_amdgcn_ballot_w64(in && right_r[k]);
                 const unsigned long long mine = right_r[k] ? br : bl;
@@ -688,7 +819,7 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
                 lbase += (int)__builtin_popcountll(bl);
                 rbase += (int)__builtin_popcountll(br);
             }
-            __syncthreads();
+            bs_sync();
         }
         // ---- next node: left child, else right child, else the most recent pending sibling ----------------------------
         if (act[0]) {
@@ -710,13 +841,14 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
             nd = next[1];
         } else if (sp > 0) {
             sp--;
-            __syncthreads();
+            bs_sync();
             const float* e = l_stk[sp];
             for (int k = 0; k < 3; k++) {
                 nd.lo[k] = e[k]; nd.hi[k] = e[3 + k]; nd.clo[k] = e[6 + k]; nd.chi[k] = e[9 + k];
             }
             nd.id = (int)rt_f2u(e[12]); nd.depth = (int)rt_f2u(e[13]); nd.a = (int)rt_f2u(e[14]); nd.cnt = (int)rt_f2u(e[15]);
-            __syncthreads();
+            bs_make_uniform(nd);
+            bs_sync();
         } else {
             have = false;
         }
