@@ -374,6 +374,7 @@ struct rt_context {
     // a scene built on the device (rt_build_scene_device): topology and vertices kept for rebuilds
     BuiltData bd;
     int build_gen = 2;  // RT_BUILD_GEN=1 selects the first-generation level loop (no small-subtree kernel)
+    int build_small_max = 256, build_tiny = 8;  // tuning: RT_BUILD_SMALL_MAX = 128 | 256, RT_BUILD_TINY = 0 | 4 | 8
     hipEvent_t build_ev0 = nullptr, build_ev1 = nullptr;
     // its reference-layout copy, made on demand for rt_get_built_scene
     float* d_ref_nodes = nullptr;
@@ -746,6 +747,8 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_PATHS_GEN")) c->use_paths2 = atoi(e) == 2;
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
+    if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
     hipDeviceProp_t prop;
     c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
                      ? prop.multiProcessorCount : 256;
@@ -972,8 +975,8 @@ static int build_core(rt_context* c) {
     BuiltData& bd = c->bd;
     const int nf = bd.nf, max_nodes = 2 * nf;
     const bool v1 = c->build_gen == 1;  // first-generation level loop all the way down (kept as the cross-check)
-    const int small_max = v1 ? 0 : BS_MAX;
-    const size_t max_active = v1 ? (size_t)nf / 2 + 2 : (size_t)nf / (size_t)BS_MAX + 1024;
+    const int small_max = v1 ? 0 : c->build_small_max;
+    const size_t max_active = v1 ? (size_t)nf / 2 + 2 : (size_t)nf / (size_t)small_max + 1024;
     hipStream_t st = c->stream;
     BuildState& s = bd.s;
     size_t ws_next = 0;
@@ -1082,7 +1085,15 @@ static int build_core(rt_context* c) {
         levels++;
     }
     if (h_counters[4] > 0) {
-        hipLaunchKernelGGL(k_build_small, dim3(h_counters[4]), dim3(64), 0, st, s, cur, h_counters[4]);
+        const dim3 gs(h_counters[4]), bs(64);
+        const int ns = h_counters[4], tiny = c->build_tiny;
+#define SMALL(M_, T_) hipLaunchKernelGGL((k_build_small<M_, T_>), gs, bs, 0, st, s, cur, ns)
+        if (small_max == 128) {
+            if (tiny == 0) SMALL(128, 0); else if (tiny == 4) SMALL(128, 4); else SMALL(128, 8);
+        } else {
+            if (tiny == 0) SMALL(256, 0); else if (tiny == 4) SMALL(256, 4); else SMALL(256, 8);
+        }
+#undef SMALL
         BCHK(hipGetLastError());
         BCHK(hipMemcpyAsync(h_counters, s.counters, sizeof h_counters, hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));

@@ -22,6 +22,8 @@
 #ifndef RT_BUILD_H
 #define RT_BUILD_H
 
+#include <type_traits>
+
 #include "rt_device.h"
 
 #define BB_BINS 16
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_partition2(BuildState s, int
 }
 
 // ---- small subtrees: one wavefront finishes a node of at most BS_MAX triangles -------------------------------------
-#define BS_MAX 256        // triangles per small subtree
-#define BS_DIRECT 16      // at most this many triangles: candidates are evaluated straight from the triangles
+#define BS_MAX 256        // most triangles a small subtree may have (the kernel is instantiated for 128 and 256)
+#define BS_TINY_MAX 8     // most triangles of a node that a single lane finishes (second phase of the kernel)
 #define BS_STACK 36       // pending right siblings, one per level below the root (depth cap 32)
 #define BS_MIN_DEPTH 9    // the level loop keeps the levels whose records the render kernels stage in LDS
 
@@ -576,6 +578,11 @@ __device__ __forceinline__ float bs_row_min(float x) {
 #undef BS_DPP_MIN
     return x;
 }
+
+// DPP helpers for scans along a row of 16 lanes: lanes whose source lies outside the row receive `ident`
+#define BS_DPP(x, ctrl, ident) ((uint32_t)__builtin_amdgcn_update_dpp((int)(ident), (int)(x), ctrl, 0xf, 0xf, false))
+#define BS_SCAN_STEP(op, x, ctrl, ident) x = op(x, BS_DPP(x, ctrl, ident))
+__device__ __forceinline__ uint32_t bs_uadd(uint32_t a, uint32_t b) { return a + b; }
 
 // Orders the LDS traffic of a one-wavefront workgroup: its DS instructions execute in program order, so a compiler
 // fence is all that is needed -- __syncthreads() would also wait for the outstanding global stores (microseconds).
@@ -605,24 +612,47 @@ __device__ __forceinline__ void bs_make_uniform(SmallNode& n) {
     n.cnt = __builtin_amdgcn_readfirstlane(n.cnt);
 }
 
+// queue entry of the second phase: centroid bounds, id | depth << 16, first position | count << 16 (the node's box is
+// the union of its triangles' boxes and is recomputed by the lane that takes the entry)
+__device__ __forceinline__ void bs_queue_put(float* e, const float* clo, const float* chi, int id, int depth, int a, int cnt) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        e[k] = clo[k];
+        e[3 + k] = chi[k];
+    }
+    e[6] = rt_u2f((uint32_t)id | ((uint32_t)depth << 16));
+    e[7] = rt_u2f((uint32_t)a | ((uint32_t)cnt << 16));
+}
+
 __device__ __forceinline__ void bs_write_entry(float4* sn, int id, const float* lo, const float* hi, int child, int a, int cnt, int rec) {
     sn[2 * id] = make_float4(lo[0], lo[1], lo[2], rt_u2f((uint32_t)child));
     sn[2 * id + 1] = make_float4(hi[0], hi[1], hi[2], rt_u2f((uint32_t)a | ((uint32_t)cnt << 12) | ((uint32_t)rec << 24)));
 }
 
+// Two phases.  (1) The wavefront walks the subtree depth-first, one node at a time, 45 lanes = 45 candidate planes.
+// Nodes of at most TINY triangles are not visited but queued.  (2) The queue is drained 64 nodes at a time, ONE LANE PER
+// NODE: with so few triangles a lane evaluates only the planes that start at one of its triangles' bins (the cost is
+// constant between them and the sweep keeps the first plane of a run), splits, and queues the children that need
+// another visit.  On a wave64 SIMD a vector instruction costs the same whether one or 64 lanes work, and tiny nodes
+// are most of the tree.
+template <int SMAX, int TINY>
 __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int num_small) {
-    __shared__ float t_ce[3][BS_MAX], t_lo[3][BS_MAX], t_hi[3][BS_MAX];  // triangle data by slot (initial position)
-    __shared__ uint32_t t_id[BS_MAX];                                       // face index by slot
-    __shared__ uint16_t l_idx[BS_MAX];                                      // position -> slot
-    __shared__ uint16_t l_leaf[BS_MAX];                                     // position -> local id of the node it ends in
+    // rings of queued nodes, by size class; queued nodes own disjoint sets of triangles (2..4 and 5..8 of them)
+    constexpr int Q4CAP = TINY > 0 ? SMAX / 2 : 1, Q8CAP = TINY > 4 ? SMAX / 4 : 1;
+    __shared__ float t_ce[3][SMAX], t_lo[3][SMAX], t_hi[3][SMAX];  // triangle data by slot (initial position)
+    __shared__ uint32_t t_id[SMAX];                                 // face index by slot
+    __shared__ uint16_t l_idx[SMAX];                                // position -> slot
+    __shared__ uint16_t l_leaf[SMAX];                               // position -> local id of the node it ends in
     __shared__ uint32_t l_bins[BB_NODE_WORDS];
     __shared__ float l_stk[BS_STACK][16];
+    __shared__ float l_q4[Q4CAP][8], l_q8[Q8CAP][8];
+    __shared__ int l_cnt[5];                                        // second phase: nodes, records, max depth, queue tails
     __shared__ int l_alloc[2];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= num_small) return;
     const int root = s.small[blockIdx.x];
     const int start = s.nstart[root], n = s.ncount[root];
-    if (n > BS_MAX || n < 2) return;  // cannot happen (k_build_split hands over 2..BS_MAX triangles)
+    if (n > SMAX || n < 2) return;  // cannot happen (k_build_split hands over 2..SMAX triangles)
     float4* sn = s.scratch + (size_t)start * 4;
 
     for (int p = lane; p < n; p += 64) {
@@ -648,8 +678,18 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
         nd.cnt = n;
         bs_make_uniform(nd);
     }
-    int m = 1, nrec = 0, maxd = nd.depth, sp = 0;
+    int m = 1, nrec = 0, maxd = nd.depth, sp = 0, qt4 = 0, qt8 = 0;
     bool have = true;
+    if (TINY > 0 && n <= TINY) {  // the whole subtree is one lane's work
+        if (n <= 4) {
+            if (lane == 0) bs_queue_put(l_q4[0], nd.clo, nd.chi, nd.id, nd.depth, nd.a, nd.cnt);
+            qt4 = 1;
+        } else {
+            if (lane == 0) bs_queue_put(l_q8[0], nd.clo, nd.chi, nd.id, nd.depth, nd.a, nd.cnt);
+            qt8 = 1;
+        }
+        have = false;
+    }
     bs_sync();
 
     while (have) {
@@ -674,24 +714,7 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
         float Llo[3] = {RT_INF, RT_INF, RT_INF}, Lhi[3] = {-RT_INF, -RT_INF, -RT_INF};
         float Rlo[3] = {RT_INF, RT_INF, RT_INF}, Rhi[3] = {-RT_INF, -RT_INF, -RT_INF};
         int lc = 0, rc = 0;
-        if (cnt <= BS_DIRECT) {
-            // few triangles: every candidate lane unions them directly, operands broadcast from the owning lanes
-            const int pk = q_b[0] | (q_b[1] << 4) | (q_b[2] << 8);
-            for (int k = 0; k < cnt; k++) {
-                const int bk = (__builtin_amdgcn_readlane(pk, k) >> (4 * ax)) & 15;
-                const float lo0 = bs_bcast(q_lo[0], k), lo1 = bs_bcast(q_lo[1], k), lo2 = bs_bcast(q_lo[2], k);
-                const float hi0 = bs_bcast(q_hi[0], k), hi1 = bs_bcast(q_hi[1], k), hi2 = bs_bcast(q_hi[2], k);
-                if (bk <= spl) {
-                    Llo[0] = fminf(Llo[0], lo0); Llo[1] = fminf(Llo[1], lo1); Llo[2] = fminf(Llo[2], lo2);
-                    Lhi[0] = fmaxf(Lhi[0], hi0); Lhi[1] = fmaxf(Lhi[1], hi1); Lhi[2] = fmaxf(Lhi[2], hi2);
-                    lc++;
-                } else {
-                    Rlo[0] = fminf(Rlo[0], lo0); Rlo[1] = fminf(Rlo[1], lo1); Rlo[2] = fminf(Rlo[2], lo2);
-                    Rhi[0] = fmaxf(Rhi[0], hi0); Rhi[1] = fmaxf(Rhi[1], hi1); Rhi[2] = fmaxf(Rhi[2], hi2);
-                    rc++;
-                }
-            }
-        } else {
+        {
             for (int k = lane; k < BB_NODE_WORDS; k += 64) {
                 const uint32_t w = (uint32_t)(k % BB_WORDS);
                 l_bins[k] = w == 0 ? 0u : (w <= 3 ? BB_KEY_POS_INF : BB_KEY_NEG_INF);
@@ -711,21 +734,40 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
                     bb_accumulate(l_bins + (a2 * BB_BINS + bb_bin(t_ce[a2][slot], nd.clo[a2], nd.chi[a2])) * BB_WORDS, lo, hi);
             }
             bs_sync();
-            for (int b = 0; b < BB_BINS; b++) {
-                const uint32_t* w = l_bins + (ax * BB_BINS + b) * BB_WORDS;
-                const int c = (int)w[0];
-                const float lo0 = bb_unkey(w[1]), lo1 = bb_unkey(w[2]), lo2 = bb_unkey(w[3]);
-                const float hi0 = bb_unkey(w[4]), hi1 = bb_unkey(w[5]), hi2 = bb_unkey(w[6]);
-                if (b <= spl) {
-                    Llo[0] = fminf(Llo[0], lo0); Llo[1] = fminf(Llo[1], lo1); Llo[2] = fminf(Llo[2], lo2);
-                    Lhi[0] = fmaxf(Lhi[0], hi0); Lhi[1] = fmaxf(Lhi[1], hi1); Lhi[2] = fmaxf(Lhi[2], hi2);
-                    lc += c;
-                } else {
-                    Rlo[0] = fminf(Rlo[0], lo0); Rlo[1] = fminf(Rlo[1], lo1); Rlo[2] = fminf(Rlo[2], lo2);
-                    Rhi[0] = fmaxf(Rhi[0], hi0); Rhi[1] = fmaxf(Rhi[1], hi1); Rhi[2] = fmaxf(Rhi[2], hi2);
-                    rc += c;
-                }
-            }
+            // every lane takes ITS bin; the unions left and right of each plane are prefix / suffix scans along the row
+            const uint32_t* w = l_bins + (ax * BB_BINS + spl) * BB_WORDS;
+            const uint32_t c = w[0];
+            uint32_t pc = c, p1 = w[1], p2 = w[2], p3 = w[3], p4 = w[4], p5 = w[5], p6 = w[6];
+            uint32_t sc = pc, s1 = p1, s2 = p2, s3 = p3, s4 = p4, s5 = p5, s6 = p6;
+#define BS_SCAN(ctrl)                                                                                          \
+    BS_SCAN_STEP(bs_uadd, pc, 0x110 + ctrl, 0u);                                                               \
+    BS_SCAN_STEP(bb_umin, p1, 0x110 + ctrl, BB_KEY_POS_INF);                                                   \
+    BS_SCAN_STEP(bb_umin, p2, 0x110 + ctrl, BB_KEY_POS_INF);                                                   \
+    BS_SCAN_STEP(bb_umin, p3, 0x110 + ctrl, BB_KEY_POS_INF);                                                   \
+    BS_SCAN_STEP(bb_umax, p4, 0x110 + ctrl, BB_KEY_NEG_INF);                                                   \
+    BS_SCAN_STEP(bb_umax, p5, 0x110 + ctrl, BB_KEY_NEG_INF);                                                   \
+    BS_SCAN_STEP(bb_umax, p6, 0x110 + ctrl, BB_KEY_NEG_INF);                                                   \
+    BS_SCAN_STEP(bs_uadd, sc, 0x100 + ctrl, 0u);                                                               \
+    BS_SCAN_STEP(bb_umin, s1, 0x100 + ctrl, BB_KEY_POS_INF);                                                   \
+    BS_SCAN_STEP(bb_umin, s2, 0x100 + ctrl, BB_KEY_POS_INF);                                                   \
+    BS_SCAN_STEP(bb_umin, s3, 0x100 + ctrl, BB_KEY_POS_INF);                                                   \
+    BS_SCAN_STEP(bb_umax, s4, 0x100 + ctrl, BB_KEY_NEG_INF);                                                   \
+    BS_SCAN_STEP(bb_umax, s5, 0x100 + ctrl, BB_KEY_NEG_INF);                                                   \
+    BS_SCAN_STEP(bb_umax, s6, 0x100 + ctrl, BB_KEY_NEG_INF)
+            BS_SCAN(1);  // row_shr:n feeds the prefixes (bins 0..plane), row_shl:n the suffixes (bins plane..15)
+            BS_SCAN(2);
+            BS_SCAN(4);
+            BS_SCAN(8);
+#undef BS_SCAN
+            // right side of plane spl = suffix of bin spl + 1
+            lc = (int)pc;
+            rc = (int)BS_DPP(sc, 0x101, 0u);
+            Llo[0] = bb_unkey(p1); Llo[1] = bb_unkey(p2); Llo[2] = bb_unkey(p3);
+            Lhi[0] = bb_unkey(p4); Lhi[1] = bb_unkey(p5); Lhi[2] = bb_unkey(p6);
+            Rlo[0] = bb_unkey(BS_DPP(s1, 0x101, BB_KEY_POS_INF)); Rlo[1] = bb_unkey(BS_DPP(s2, 0x101, BB_KEY_POS_INF));
+            Rlo[2] = bb_unkey(BS_DPP(s3, 0x101, BB_KEY_POS_INF));
+            Rhi[0] = bb_unkey(BS_DPP(s4, 0x101, BB_KEY_NEG_INF)); Rhi[1] = bb_unkey(BS_DPP(s5, 0x101, BB_KEY_NEG_INF));
+            Rhi[2] = bb_unkey(BS_DPP(s6, 0x101, BB_KEY_NEG_INF));
         }
         // same cost expressions as k_build_split; RT_INF = "not a candidate"
         const float leaf_cost = (50.0f * (float)cnt) * bb_area6(nd.lo, nd.hi);
@@ -782,15 +824,25 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
                 ch.cnt = side ? cnt - nl : nl;
                 act[side] = ch.cnt >= 2 && ch.depth < BB_MAX_DEPTH;
                 if (!act[side] && lane == side) bs_write_entry(sn, ch.id, ch.lo, ch.hi, -1, ch.a, ch.cnt, 0);
+                if (TINY > 0 && act[side] && ch.cnt <= TINY) {  // left to the second phase
+                    if (ch.cnt <= 4) {
+                        if (lane == side) bs_queue_put(l_q4[qt4 & (Q4CAP - 1)], ch.clo, ch.chi, ch.id, ch.depth, ch.a, ch.cnt);
+                        qt4++;
+                    } else {
+                        if (lane == side) bs_queue_put(l_q8[qt8 & (Q8CAP - 1)], ch.clo, ch.chi, ch.id, ch.depth, ch.a, ch.cnt);
+                        qt8++;
+                    }
+                    act[side] = false;
+                }
             }
             // ---- stable partition of the node's positions (at most BS_MAX / 64 chunks, all read before any write) ----
-            uint32_t slot_r[BS_MAX / 64];
-            bool right_r[BS_MAX / 64];
+            uint32_t slot_r[SMAX / 64];
+            bool right_r[SMAX / 64];
             slot_r[0] = slot0;
             right_r[0] = in0 && (best_axis == 0 ? q_b[0] : (best_axis == 1 ? q_b[1] : q_b[2])) > best_bin;
             if (cnt > 64) {
 #pragma unroll
-                for (int k = 1; k < BS_MAX / 64; k++) {
+                for (int k = 1; k < SMAX / 64; k++) {
                     const int p = k * 64 + lane;
                     slot_r[k] = 0;
                     right_r[k] = false;
@@ -803,7 +855,7 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
             }
             int lbase = 0, rbase = 0;
 #pragma unroll
-            for (int k = 0; k < BS_MAX / 64; k++) {
+            for (int k = 0; k < SMAX / 64; k++) {
                 if (k > 0 && cnt <= 64 * k) break;
                 const int p = k * 64 + lane;
                 const bool in = p < cnt;
@@ -852,6 +904,176 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState s, int cur, int n
         } else {
             have = false;
         }
+    }
+
+    // ---- second phase: one lane per queued node -----------------------------------------------------------------------------
+    if (TINY > 0 && (qt4 > 0 || qt8 > 0)) {
+        if (lane == 0) {
+            l_cnt[0] = m;
+            l_cnt[1] = nrec;
+            l_cnt[2] = maxd;
+            l_cnt[3] = qt4;
+            l_cnt[4] = qt8;
+        }
+        int head4 = 0, head8 = 0;
+        // one batch: up to 64 nodes of at most TN triangles each, popped from `ring`
+        auto batch = [&](auto tn_tag, float (*ring)[8], int cap_mask, int& head, int tail) {
+            constexpr int TN = decltype(tn_tag)::value;
+            const int avail = tail - head;
+            const int nb = avail < 64 ? avail : 64;
+            const bool on = lane < nb;
+            float clo[3] = {0.0f, 0.0f, 0.0f}, chi[3] = {0.0f, 0.0f, 0.0f};
+            int id = 0, depth = 0, a = 0, cnt = 0;
+            if (on) {
+                const float* e = ring[(head + lane) & cap_mask];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    clo[k] = e[k];
+                    chi[k] = e[3 + k];
+                }
+                const uint32_t w0 = rt_f2u(e[6]), w1 = rt_f2u(e[7]);
+                id = (int)(w0 & 0xffffu); depth = (int)(w0 >> 16); a = (int)(w1 & 0xffffu); cnt = (int)(w1 >> 16);
+            }
+            head += nb;
+            bs_sync();  // every entry of the batch is in registers before anything is appended
+            if (!on) return;
+            // the node's triangles (slot, box, packed bins) and its box, the union of theirs
+            uint32_t slot[TN];
+            float tlo[TN][3], thi[TN][3];
+            int tb[TN];
+            float nlo[3] = {RT_INF, RT_INF, RT_INF}, nhi[3] = {-RT_INF, -RT_INF, -RT_INF};
+#pragma unroll
+            for (int i = 0; i < TN; i++) {
+                slot[i] = 0u;
+                tb[i] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    tlo[i][k] = RT_INF;
+                    thi[i][k] = -RT_INF;
+                }
+                if (i < cnt) {
+                    slot[i] = l_idx[a + i];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        tlo[i][k] = t_lo[k][slot[i]];
+                        thi[i][k] = t_hi[k][slot[i]];
+                        tb[i] |= bb_bin(t_ce[k][slot[i]], clo[k], chi[k]) << (4 * k);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    nlo[k] = fminf(nlo[k], tlo[i][k]);
+                    nhi[k] = fmaxf(nhi[k], thi[i][k]);
+                }
+            }
+            // candidates: per axis the planes that start at a triangle's bin; cost and tie rules of k_build_split
+            const float leaf_cost = (50.0f * (float)cnt) * bb_area6(nlo, nhi);
+            float bcost = RT_INF;
+            int bax = 0, bsp = 0, bnl = 0;
+            float BLlo[3], BLhi[3], BRlo[3], BRhi[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                BLlo[k] = BRlo[k] = RT_INF;
+                BLhi[k] = BRhi[k] = -RT_INF;
+            }
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) {
+#pragma unroll
+                for (int i = 0; i < TN; i++) {
+                    const int spl = (tb[i] >> (4 * ax)) & 15;
+                    float Llo[3] = {RT_INF, RT_INF, RT_INF}, Lhi[3] = {-RT_INF, -RT_INF, -RT_INF};
+                    float Rlo[3] = {RT_INF, RT_INF, RT_INF}, Rhi[3] = {-RT_INF, -RT_INF, -RT_INF};
+                    int lc = 0, rc = 0;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        const bool valid = j < cnt;
+                        const bool inL = valid && ((tb[j] >> (4 * ax)) & 15) <= spl;
+                        const bool inR = valid && !inL;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            Llo[k] = fminf(Llo[k], inL ? tlo[j][k] : RT_INF);
+                            Lhi[k] = fmaxf(Lhi[k], inL ? thi[j][k] : -RT_INF);
+                            Rlo[k] = fminf(Rlo[k], inR ? tlo[j][k] : RT_INF);
+                            Rhi[k] = fmaxf(Rhi[k], inR ? thi[j][k] : -RT_INF);
+                        }
+                        lc += inL ? 1 : 0;
+                        rc += inR ? 1 : 0;
+                    }
+                    if (i < cnt && rc > 0 && depth < BB_MAX_DEPTH) {
+                        const float cst = (1.0f + (50.0f * (float)lc) * bb_area6(Llo, Lhi)) + (50.0f * (float)rc) * bb_area6(Rlo, Rhi);
+                        if (cst < leaf_cost && (cst < bcost || (cst == bcost && ax == bax && spl < bsp))) {
+                            bcost = cst;
+                            bax = ax;
+                            bsp = spl;
+                            bnl = lc;
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                BLlo[k] = Llo[k]; BLhi[k] = Lhi[k]; BRlo[k] = Rlo[k]; BRhi[k] = Rhi[k];
+                            }
+                        }
+                    }
+                }
+            }
+            if (!(bcost < RT_INF)) {
+                bs_write_entry(sn, id, nlo, nhi, -1, a, cnt, 0);  // leaf
+                return;
+            }
+            const int c0 = atomicAdd(&l_cnt[0], 2), rec = atomicAdd(&l_cnt[1], 1);
+            atomicMax(&l_cnt[2], depth + 1);
+            bs_write_entry(sn, id, nlo, nhi, c0, a, cnt, rec);
+            const float ca = bs_sel(bax, clo[0], clo[1], clo[2]), cb2 = bs_sel(bax, chi[0], chi[1], chi[2]);
+            const float plane = ca + (cb2 - ca) * ((float)(bsp + 1) / (float)BB_BINS);
+            int li = 0, ri = 0;  // stable partition of the node's positions
+#pragma unroll
+            for (int i = 0; i < TN; i++) {
+                if (i < cnt) {
+                    const bool right = ((tb[i] >> (4 * bax)) & 15) > bsp;
+                    const int dest = a + (right ? bnl + ri : li);
+                    li += right ? 0 : 1;
+                    ri += right ? 1 : 0;
+                    l_idx[dest] = (uint16_t)slot[i];
+                    l_leaf[dest] = (uint16_t)(c0 + (right ? 1 : 0));
+                }
+            }
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                float lo2[3], hi2[3], cl2[3], ch2[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    lo2[k] = side ? BRlo[k] : BLlo[k];
+                    hi2[k] = side ? BRhi[k] : BLhi[k];
+                    float ccl = clo[k], cch = chi[k];
+                    if (k == bax) {
+                        if (side) ccl = plane; else cch = plane;
+                    }
+                    cl2[k] = fmaxf(ccl, lo2[k]);
+                    ch2[k] = fminf(cch, hi2[k]);
+                }
+                const int a2 = side ? a + bnl : a, cnt2 = side ? cnt - bnl : bnl;
+                if (cnt2 >= 2 && depth + 1 < BB_MAX_DEPTH) {
+                    if (cnt2 <= 4)
+                        bs_queue_put(l_q4[atomicAdd(&l_cnt[3], 1) & (Q4CAP - 1)], cl2, ch2, c0 + side, depth + 1, a2, cnt2);
+                    else
+                        bs_queue_put(l_q8[atomicAdd(&l_cnt[4], 1) & (Q8CAP - 1)], cl2, ch2, c0 + side, depth + 1, a2, cnt2);
+                } else {
+                    bs_write_entry(sn, c0 + side, lo2, hi2, -1, a2, cnt2, 0);
+                }
+            }
+        };
+        for (;;) {
+            bs_sync();
+            const int tail4 = __builtin_amdgcn_readfirstlane(l_cnt[3]), tail8 = __builtin_amdgcn_readfirstlane(l_cnt[4]);
+            if (TINY > 4 && tail8 > head8)
+                batch(std::integral_constant<int, (TINY > 4 ? TINY : 1)>{}, l_q8, Q8CAP - 1, head8, tail8);
+            else if (tail4 > head4)
+                batch(std::integral_constant<int, 4>{}, l_q4, Q4CAP - 1, head4, tail4);
+            else
+                break;
+        }
+        bs_sync();
+        m = __builtin_amdgcn_readfirstlane(l_cnt[0]);
+        nrec = __builtin_amdgcn_readfirstlane(l_cnt[1]);
+        maxd = __builtin_amdgcn_readfirstlane(l_cnt[2]);
     }
 
     // ---- ids for the new nodes and records, then copy the subtree out --------------------------------------------------

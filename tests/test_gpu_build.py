@@ -134,27 +134,41 @@ def _canonical(scene):
     return rows, per_face
 
 
-@pytest.mark.parametrize("name", ["teapot", "dragon80k", "soup"])
+BUILDER_VARIANTS = {  # environment read by rt_create
+    "level loop only": {"RT_BUILD_GEN": "1"},
+    "default": {},
+    "small 128, tiny 4": {"RT_BUILD_SMALL_MAX": "128", "RT_BUILD_TINY": "4"},
+    "small 128, tiny 8": {"RT_BUILD_SMALL_MAX": "128", "RT_BUILD_TINY": "8"},
+    "small 256, tiny 0": {"RT_BUILD_SMALL_MAX": "256", "RT_BUILD_TINY": "0"},
+    "small 256, tiny 4": {"RT_BUILD_SMALL_MAX": "256", "RT_BUILD_TINY": "4"},
+}
+
+
+@pytest.mark.parametrize("name", ["model", "teapot", "dragon80k", "soup"])
 def test_small_subtree_kernel_builds_the_same_tree_as_the_level_loop(pkg, name):
-    """The second-generation builder (segment-walking level loop + one wavefront per small subtree) must produce
-    exactly the tree of the plain level-synchronous builder: same boxes, same leaves."""
+    """The second-generation builder (segment-walking level loop, one wavefront per small subtree, one lane per tiny
+    node) must produce exactly the tree of the plain level-synchronous builder, in every tuning variant: same boxes,
+    same leaves."""
     v, f = _soup() if name == "soup" else _read_obj(pkg, name)
     col = pkg.make_colours(2, f.shape[0])
     built = {}
-    for gen in ("1", "2"):
-        os.environ["RT_BUILD_GEN"] = gen
+    for variant, env in BUILDER_VARIANTS.items():
+        os.environ.update(env)
         try:
             ctx = pkg.RenderContext(0)
         finally:
-            del os.environ["RT_BUILD_GEN"]
-        built[gen], ms = ctx.build_scene_device(v, f, col)
-        print(f"\n[gpu build] {name} generation {gen}: {built[gen].num_nodes} nodes, {ms:.2f} ms", flush=True)
+            for k in env:
+                del os.environ[k]
+        built[variant], ms = ctx.build_scene_device(v, f, col)
+        print(f"\n[gpu build] {name}, {variant}: {built[variant].num_nodes} nodes, {ms:.2f} ms", flush=True)
         ctx.close()
-    assert built["1"].num_nodes == built["2"].num_nodes
-    rows1, faces1 = _canonical(built["1"])
-    rows2, faces2 = _canonical(built["2"])
-    assert np.array_equal(rows1, rows2)
-    assert np.array_equal(faces1, faces2)
+    rows1, faces1 = _canonical(built["level loop only"])
+    for variant, b in built.items():
+        assert b.num_nodes == built["level loop only"].num_nodes, variant
+        _validate_tree(b, v, f)
+        rows2, faces2 = _canonical(b)
+        assert np.array_equal(rows1, rows2), variant
+        assert np.array_equal(faces1, faces2), variant
 
 
 def test_rebuild_from_device_vertices(pkg, oracle):
