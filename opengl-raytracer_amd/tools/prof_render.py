@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-SCENES = {"dragon80k": ("dragon80k.obj", (0.0, 0.0, -5.5)), "teapot": ("teapot.obj", (0.0, 0.0, -2.0))}
+SCENES = {"dragon80k": ("dragon80k.obj", (0.0, 0.0, -5.5)), "teapot": ("teapot.obj", (0.0, 0.0, -2.0)),
+          "grid": (None, (0.0, 0.0, -30.0))}  # grid: ~9.3M triangles, tree built on the GPU
 
 
 def main():
@@ -28,10 +29,19 @@ def main():
     a = ap.parse_args()
     pkg = entry.load_package()
     obj, pos = SCENES[a.scene]
-    scene = pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1)
     cam = pkg.make_camera(pos=pos)
     ctx = pkg.RenderContext(0)
-    ctx.upload_scene(scene)
+    if obj is None:
+        import numpy as np
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import gen_scenes
+
+        fx = os.path.join(ROOT, "fixtures")
+        v, f = gen_scenes.grid([os.path.join(fx, "dragon80k.obj")] * 3 + [os.path.join(fx, "teapot.obj")], (6, 5, 5), 8.0, 7)
+        ctx.build_scene_device(v.astype(np.float32), f.astype(np.uint32), pkg.make_colours(1, f.shape[0]), download=False)
+    else:
+        ctx.upload_scene(pkg.load_scene(os.path.join(ROOT, "fixtures", obj), colour_seed=1))
     flags = {"paths": 0, "wavefront": pkg.RT_FLAG_WAVEFRONT, "megakernel": pkg.RT_FLAG_MEGAKERNEL}[a.pipeline] | (pkg.RT_FLAG_FIX_INVDIR if a.fix_invdir else 0)
     if a.primary_only:
         t0 = time.perf_counter()
