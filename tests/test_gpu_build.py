@@ -216,6 +216,45 @@ def test_rebuild_from_device_vertices(pkg, oracle):
     ctx.close()
 
 
+def test_device_build_degenerate_inputs(pkg, oracle):
+    """Inputs that defeat the SAH: many identical triangles (no plane separates their centroids, so they end in one big
+    leaf), zero-area triangles, a flat mesh (one axis has no extent) -- the build must terminate with a valid tree and
+    render like the oracle."""
+    rng = np.random.RandomState(3)
+    tri = np.array([[-1, -1, 4], [1, -1, 4], [0, 1, 4]], dtype=np.float32)
+    same = np.tile(tri, (1000, 1))                                                # 1000 copies of one triangle
+    flat = np.concatenate([rng.uniform(-3, 3, (600, 2)), np.full((600, 1), 6.0)], axis=1).astype(np.float32)
+    line = np.stack([np.linspace(-2, 2, 30), np.zeros(30), np.full(30, 5.0)], axis=1).astype(np.float32)  # collinear
+    v = np.concatenate([same, flat, line]).astype(np.float32)
+    f_same = np.arange(3000, dtype=np.uint32).reshape(-1, 3)
+    f_flat = (3000 + rng.randint(0, 600, (400, 3))).astype(np.uint32)
+    f_line = (3600 + rng.randint(0, 30, (50, 3))).astype(np.uint32)              # zero-area
+    f = np.concatenate([f_same, f_flat, f_line])
+    col = pkg.make_colours(9, f.shape[0])
+    cam = pkg.make_camera(pos=(0.0, 0.0, -2.0))
+    trees = {}
+    for variant in ("level loop only", "default"):
+        os.environ.update(BUILDER_VARIANTS[variant])
+        try:
+            ctx = pkg.RenderContext(0)
+        finally:
+            for k in BUILDER_VARIANTS[variant]:
+                del os.environ[k]
+        built, _ = ctx.build_scene_device(v, f, col)
+        max_leaf = _validate_tree(built, v, f)
+        assert max_leaf >= 1000                                                   # the identical triangles share a leaf
+        p = pkg.make_params(320, 180, frames=2, flags=pkg.RT_FLAG_COUNTERS)
+        ctx.reset_counters()
+        got = ctx.render(cam, p)
+        cnt = ctx.counters()
+        want, cnt_o = oracle.render(built, cam, p)
+        assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+        trees[variant] = _canonical(built)
+        ctx.close()
+    assert np.array_equal(trees["default"][0], trees["level loop only"][0])
+    assert np.array_equal(trees["default"][1], trees["level loop only"][1])
+
+
 def test_device_build_rejects_bad_input(pkg):
     ctx = pkg.RenderContext(0)
     v = np.zeros((3, 3), dtype=np.float32)
