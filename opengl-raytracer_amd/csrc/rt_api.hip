@@ -882,6 +882,8 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     for (int i = 0; i < V; i++)
         if (!order[i].leaf && rec_of[i] < 0) rec_of[i] = next_rec++;
     // Pass 3: fill the records.
+    // the path kernel addresses records and triangle records with 32-bit byte offsets: at most 2^26 of each
+    if (num_inner >= (1 << 26) || T >= (1 << 26)) return fail(c, RT_ELIMIT, "more than 2^26 - 1 inner nodes or triangles");
     std::vector<float> recs((size_t)num_inner * 16, 0.0f);  // 16 floats per inner node
     std::vector<float> tris;                                 // 16 floats per leaf-ordered triangle
     tris.reserve((size_t)T * 16);
@@ -1136,7 +1138,7 @@ int rt_build_scene_device(rt_context* c, const float* vertices, int32_t num_vert
     if (!c) return RT_EINVAL;
     if (!vertices || !faces || !face_colours) return fail(c, RT_EINVAL, "NULL argument");
     if (num_vertices < 1 || num_faces < 1) return fail(c, RT_EINVAL, "need at least one vertex and one face");
-    if ((int64_t)num_faces > (int64_t)0x3ffffff0) return fail(c, RT_ELIMIT, "too many faces");
+    if ((int64_t)num_faces >= (int64_t)(1 << 26)) return fail(c, RT_ELIMIT, "more than 2^26 - 1 faces");
     for (int64_t i = 0; i < (int64_t)num_faces * 3; i++)
         if (faces[i] >= (uint32_t)num_vertices) return fail(c, RT_EINVAL, "face %lld references vertex %u of %d", (long long)(i / 3), faces[i], num_vertices);
     HIPCHK(c, hipSetDevice(c->device));

@@ -102,18 +102,26 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     const uint32_t nodes_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&s_nodes[0];
     uint2* const spill = a.spill ? a.spill + ((size_t)blockIdx.x * PT_BLOCK + tid) : nullptr;
     const size_t spill_stride = a.spill_stride;
+    // LDS stack entries are addressed with 32-bit LDS offsets and a 24-bit multiply: through the generic pointer the
+    // compiler computes every entry address with a 64-bit v_mad_u64_u32, which issues at a quarter of the rate
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) u32x2 lds_uint2;
+    const uint32_t stack_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)&s_stack[0][tid];
+#define PT_SLOT(i_) ((lds_uint2*)(uintptr_t)(stack_lds + __umul24((uint32_t)(i_), (uint32_t)(PT_BLOCK * sizeof(uint2)))))
 #define PT_PUT(i_, ref_, dist_)                                              \
     do {                                                                     \
         uint2 v_ = make_uint2((uint32_t)(ref_), rt_f2u(dist_));             \
         if ((i_) < PT_STACK)                                                 \
-            s_stack[(i_)][tid] = v_;                                         \
+            *PT_SLOT(i_) = u32x2{v_.x, v_.y};                                \
         else                                                                 \
             spill_store(spill + (size_t)((i_)-PT_STACK) * spill_stride, v_); \
     } while (0)
 #define PT_GET(e_, i_)                                                       \
     do {                                                                     \
-        if ((i_) < PT_STACK)                                                 \
-            e_ = s_stack[(i_)][tid];                                         \
+        if ((i_) < PT_STACK) {                                               \
+            const u32x2 w_ = *PT_SLOT(i_);                                   \
+            e_ = make_uint2(w_.x, w_.y);                                     \
+        }                                                                    \
         else                                                                 \
             e_ = spill_load(spill + (size_t)((i_)-PT_STACK) * spill_stride); \
     } while (0)
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         const unsigned long long staged = __builtin_amdgcn_ballot_w64(cur < a.cache_recs);
                         const uint32_t cc = (uint32_t)cur;
                         const uint32_t base = nodes_lds + (cc << 6), x = (cc >> 2) & 3u;
-                        const float4* rec = sc.nodes + (size_t)cc * 4;
+                        const uint32_t rec_off = cc << 6;  // byte offset from sc.nodes (the upload limits records to 4 GiB)
                         unsigned long long keep;
                         asm volatile(
                             "s_mov_b64 %4, exec\n\t"
@@ -278,15 +286,15 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                             "ds_read_b128 %2, %8\n\t"
                             "ds_read_b128 %3, %9\n\t"
                             "s_andn2_b64 exec, %4, %5\n\t"
-                            "global_load_dwordx4 %0, %10, off\n\t"
-                            "global_load_dwordx4 %1, %10, off offset:16\n\t"
-                            "global_load_dwordx4 %2, %10, off offset:32\n\t"
-                            "global_load_dwordx4 %3, %10, off offset:48\n\t"
+                            "global_load_dwordx4 %0, %10, %11\n\t"
+                            "global_load_dwordx4 %1, %10, %11 offset:16\n\t"
+                            "global_load_dwordx4 %2, %10, %11 offset:32\n\t"
+                            "global_load_dwordx4 %3, %10, %11 offset:48\n\t"
                             "s_mov_b64 exec, %4\n\t"
                             "s_waitcnt vmcnt(0) lgkmcnt(0)"
                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&s"(keep)
                             : "s"(staged), "v"(base + (x << 4)), "v"(base + ((1u ^ x) << 4)), "v"(base + ((2u ^ x) << 4)),
-                              "v"(base + ((3u ^ x) << 4)), "v"(rec)
+                              "v"(base + ((3u ^ x) << 4)), "v"(rec_off), "s"(sc.nodes)
                             : "memory");
                     }
                     if (COUNT) {
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     bool last = true;
                     if (cur != RT_REF_EMPTY) {
                         const int k = ~cur;
-                        const float4* tr = sc.tris + (size_t)k * 4;
+                        const float4* tr = (const float4*)((const char*)sc.tris + ((uint32_t)k << 6));  // 32-bit offset
                         float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
                         if (COUNT) cn.tri++;
                         float t = tri_dist(p.o, p.d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
@@ -350,6 +358,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
 #undef DIAG
 #undef PT_PUT
 #undef PT_GET
+#undef PT_SLOT
 }
 
 // Folds the staged samples of one batch into the framebuffer, frame by frame in order:
