@@ -73,6 +73,8 @@ def main() -> int:
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"],
                     help="N > 1: 'samples' = each GPU renders its own frames (weak scaling, the default); 'tiles' = every "
                          "GPU renders its horizontal band of every frame (strong scaling)")
+    ap.add_argument("--dynamic-update", default="rebuild", choices=["rebuild", "refit"],
+                    help="grid9m_dynamic: rebuild the BVH every step (default) or refit the first build's tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -310,7 +312,10 @@ def run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank,
     def step(k: int, extra_flags: int = 0):
         torch.sin(d_rest * 3.0 + 0.37 * k, out=d_v)
         d_v.mul_(0.01).add_(d_rest)
-        _, build_ms = ctx.rebuild_scene_device(d_v.data_ptr())
+        if args.dynamic_update == "refit":
+            _, build_ms = ctx.refit_scene_device(d_v.data_ptr())
+        else:
+            _, build_ms = ctx.rebuild_scene_device(d_v.data_ptr())
         ctx.render_device(cam, pkg.make_params(W, H, frames=1, flags=flags | extra_flags, band=band), frame.data_ptr())
         if dist is not None:
             dist.reduce(frame, dst=0)
@@ -370,7 +375,7 @@ def run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank,
             "data": "synthetic",
             "config": {
                 "workload": f"grid9m_dynamic: generated grid 6x5x5 of dragon80k/teapot ({f.shape[0]} triangles), every vertex "
-                            f"displaced per step, binned-SAH rebuild on the GPU, {W}x{H}, 1 spp, 100 bounces, Russian roulette, "
+                            f"displaced per step, binned-SAH {args.dynamic_update} on the GPU, {W}x{H}, 1 spp, 100 bounces, Russian roulette, "
                             f"{'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}",
                 "parallelism": f"replicated rebuild + tile-partition x{world}" if world > 1 else "single GPU",
             },

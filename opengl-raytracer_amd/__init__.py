@@ -115,6 +115,7 @@ HIP_SYMBOLS = [
     "rt_get_normals",
     "rt_build_scene_device",
     "rt_rebuild_scene_device",
+    "rt_refit_scene_device",
     "rt_get_built_scene",
     "rt_raytrace_frame",
     "rt_render_device",
@@ -179,6 +180,7 @@ def load_hip() -> C.CDLL:
         lib.rt_get_normals.argtypes = [vp, c_float_p]
         lib.rt_build_scene_device.argtypes = [vp, c_float_p, C.c_int32, c_uint32_p, C.c_int32, c_float_p]
         lib.rt_rebuild_scene_device.argtypes = [vp, vp]
+        lib.rt_refit_scene_device.argtypes = [vp, vp]
         lib.rt_get_built_scene.argtypes = [vp, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                            c_int32_p, c_float_p]
         lib.rt_raytrace_frame.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, vp, vp]
@@ -402,6 +404,11 @@ class RenderContext:
         """Rebuild with the faces and colours of the last build_scene_device and new vertex positions read from a
         device pointer (num_vertices x 3 floats)."""
         self._check(self.lib.rt_rebuild_scene_device(self.ctx, C.c_void_p(d_vertices_ptr)), "rt_rebuild_scene_device")
+        return self.get_built_scene(download)
+
+    def refit_scene_device(self, d_vertices_ptr: int, download: bool = False):
+        """Keep the tree of the last build, recompute its boxes from new vertex positions (device pointer)."""
+        self._check(self.lib.rt_refit_scene_device(self.ctx, C.c_void_p(d_vertices_ptr)), "rt_refit_scene_device")
         return self.get_built_scene(download)
 
     def get_built_scene(self, download: bool = True):

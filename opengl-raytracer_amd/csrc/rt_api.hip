@@ -355,6 +355,7 @@ struct BuiltData {
     int out_cap = 0;       // faces the output buffers (d_nodes, d_tris, d_shade) were sized for; 0 = not from a build
     int ref_cap = 0;       // faces the reference-layout buffers were sized for
     bool ref_valid = false;
+    bool parents_valid = false;  // nparent filled (first refit after a build)
 };
 
 struct rt_context {
@@ -1026,6 +1027,8 @@ static int build_core(rt_context* c) {
     for (auto pp : nints) BCHK(dalloc((void**)pp, (size_t)max_nodes * sizeof(int32_t)));
     BCHK(dalloc((void**)&s.bins, max_active * BB_NODE_WORDS * sizeof(uint32_t)));
     BCHK(dalloc((void**)&s.counters, 8 * sizeof(int32_t)));
+    BCHK(dalloc((void**)&s.nparent, (size_t)max_nodes * sizeof(int32_t)));
+    BCHK(dalloc((void**)&s.nflag, (size_t)max_nodes * sizeof(int32_t)));
     BCHK(dalloc((void**)&s.small, ((size_t)nf / 2 + 2) * sizeof(int32_t)));
     BCHK(dalloc((void**)&s.scratch, (size_t)nf * 4 * sizeof(float4)));
 
@@ -1117,6 +1120,7 @@ static int build_core(rt_context* c) {
 #undef BCHK
 
     bd.cur = cur;
+    bd.parents_valid = false;
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
     c->sc.shade = c->d_shade;
@@ -1174,6 +1178,39 @@ int rt_rebuild_scene_device(rt_context* c, const float* d_vertices) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(bd.d_verts, d_vertices, (size_t)bd.nv * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return build_core(c);
+}
+
+int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
+    if (!c) return RT_EINVAL;
+    if (!d_vertices) return fail(c, RT_EINVAL, "d_vertices is NULL");
+    BuiltData& bd = c->bd;
+    if (bd.nf <= 0 || !bd.d_faces || !c->built_nodes || !c->has_scene)
+        return fail(c, RT_ENOSCENE, "rt_refit_scene_device needs a scene built by rt_build_scene_device");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int nf = bd.nf, num_nodes = c->built_nodes;
+    const dim3 blk(BB_BLOCK), grid_n((num_nodes + BB_BLOCK - 1) / BB_BLOCK), grid_t((nf + BB_BLOCK - 1) / BB_BLOCK);
+    HIPCHK(c, hipMemcpyAsync(bd.d_verts, d_vertices, (size_t)bd.nv * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipEventRecord(c->build_ev0, st));
+    if (!bd.parents_valid) {
+        hipLaunchKernelGGL(k_build_parents, grid_n, blk, 0, st, bd.s, num_nodes);
+        bd.parents_valid = true;
+    }
+    HIPCHK(c, hipMemsetAsync(bd.s.nflag, 0, (size_t)num_nodes * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_build_refit, grid_n, blk, 0, st, bd.s, bd.cur, num_nodes, bd.d_verts, bd.d_faces);
+    hipLaunchKernelGGL(k_build_emit_recs, grid_n, blk, 0, st, bd.s, num_nodes, c->d_nodes);
+    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, bd.s, bd.cur, nf, bd.d_verts, bd.d_faces, bd.d_fcol, c->d_tris, c->d_shade);
+    HIPCHK(c, hipEventRecord(c->build_ev1, st));
+    float4 rlo, rhi;
+    HIPCHK(c, hipMemcpyAsync(&rlo, bd.s.nmin, sizeof rlo, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&rhi, bd.s.nmax, sizeof rhi, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&c->last_build_ms, c->build_ev0, c->build_ev1);
+    bd.ref_valid = false;
+    c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
+    c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
+    return RT_OK;
 }
 
 int rt_get_built_scene(rt_context* c, int32_t* num_nodes, int32_t* num_tris, float* nodes, float* triv0, float* triv1,

@@ -216,6 +216,47 @@ def test_rebuild_from_device_vertices(pkg, oracle):
     ctx.close()
 
 
+def test_refit_keeps_topology_and_matches_oracle(pkg, oracle):
+    """rt_refit_scene_device: the tree of the last build with boxes recomputed for new vertex positions -- same
+    topology and triangle order, tight boxes, per-tree parity with the oracle; a rebuild afterwards still works."""
+    v, f = _read_obj(pkg, "dragon80k")
+    col = pkg.make_colours(6, f.shape[0])
+    ctx = pkg.RenderContext(0)
+    d_v = pkg.DeviceBuffer.from_array(v)
+    with pytest.raises(RuntimeError):
+        ctx.refit_scene_device(d_v.ptr)                                     # nothing built yet
+    d_v.free()
+    built0, _ = ctx.build_scene_device(v, f, col)
+    cam = pkg.make_camera(pos=CAMS["dragon80k"])
+    rng = np.random.RandomState(8)
+    v2 = v
+    for step in range(2):
+        v2 = (v2 + rng.normal(0.0, 0.03, v.shape)).astype(np.float32)
+        d_v = pkg.DeviceBuffer.from_array(v2)
+        refit, ms = ctx.refit_scene_device(d_v.ptr, download=True)
+        d_v.free()
+        print(f"\n[gpu build] refit {step}: {refit.num_nodes} nodes, {ms:.3f} ms", flush=True)
+        assert np.array_equal(refit.nodes[:, 8:11], built0.nodes[:, 8:11])  # same topology
+        assert np.array_equal(refit.tri_src, built0.tri_src)                # same triangle order
+        _validate_tree(refit, v2, f)
+        ids, t = ctx.primary_hits(cam, 640, 360)
+        ids_o, t_o = oracle.primary_hits(refit, cam, 640, 360)
+        assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o))
+        for flags in (0, pkg.RT_FLAG_FIX_INVDIR):
+            p = pkg.make_params(480, 270, frames=2, flags=flags | pkg.RT_FLAG_COUNTERS)
+            ctx.reset_counters()
+            got = ctx.render(cam, p)
+            cnt = ctx.counters()
+            want, cnt_o = oracle.render(refit, cam, p)
+            assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+        assert np.array_equal(bits(ctx.get_normals()), bits(oracle.normals(refit)))
+    d_v = pkg.DeviceBuffer.from_array(v2)
+    rebuilt, _ = ctx.rebuild_scene_device(d_v.ptr, download=True)
+    d_v.free()
+    _validate_tree(rebuilt, v2, f)
+    ctx.close()
+
+
 def test_device_build_degenerate_inputs(pkg, oracle):
     """Inputs that defeat the SAH: many identical triangles (no plane separates their centroids, so they end in one big
     leaf), zero-area triangles, a flat mesh (one axis has no extent) -- the build must terminate with a valid tree and
@@ -282,17 +323,23 @@ def test_device_build_big_scene_and_animation(pkg, oracle):
     ctx = pkg.RenderContext(0)
     cam = pkg.make_camera(pos=(0.0, 0.0, -30.0))
     rng = np.random.RandomState(0)
-    for step in range(2):
+    for step in range(3):
         t0 = time.time()
         if step == 0:
             built, ms = ctx.build_scene_device(v, f, col)
         else:
             d_v = pkg.DeviceBuffer.from_array(v)
-            built, ms = ctx.rebuild_scene_device(d_v.ptr, download=True)
+            update = ctx.rebuild_scene_device if step == 1 else ctx.refit_scene_device
+            built, ms = update(d_v.ptr, download=True)
             d_v.free()
             _validate_tree(built, v, f)
+            # every inner box is exactly the union of its children's (a refit that read a stale box would not be)
+            inner = built.nodes[:, 8] == 0.0
+            a, b = built.nodes[inner, 9].astype(np.int64), built.nodes[inner, 10].astype(np.int64)
+            assert np.array_equal(built.nodes[inner, 0:3], np.minimum(built.nodes[a, 0:3], built.nodes[b, 0:3]))
+            assert np.array_equal(built.nodes[inner, 4:7], np.maximum(built.nodes[a, 4:7], built.nodes[b, 4:7]))
         wall = time.time() - t0
-        print(f"\n[gpu build] step {step}: {built.num_tris} triangles -> {built.num_nodes} nodes, device build {ms:.1f} ms "
+        print(f"\n[gpu build] step {step} ({('build', 'rebuild', 'refit')[step]}): {built.num_tris} triangles -> {built.num_nodes} nodes, device build {ms:.1f} ms "
               f"(call incl. upload + download of the tree {wall:.1f} s)", flush=True)
         p = pkg.make_params(320, 180, frames=2, flags=pkg.RT_FLAG_COUNTERS)
         ctx.reset_counters()
