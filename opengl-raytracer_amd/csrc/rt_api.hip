@@ -633,6 +633,10 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     a.min_trav = PT_MIN_TRAV;
     a.min_service = PT_MIN_SERVICE;
     // developer knobs for tuning runs
+    a.w_inner = PT_W_INNER;
+    a.w_leaf = PT_W_LEAF;
+    if (const char* e = getenv("RT_TUNE_W_INNER")) a.w_inner = atoi(e);
+    if (const char* e = getenv("RT_TUNE_W_LEAF")) a.w_leaf = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) a.min_trav = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) a.min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }

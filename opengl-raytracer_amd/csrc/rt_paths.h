@@ -38,6 +38,8 @@
 #endif
 #define PT_MIN_TRAV 40         // leave the traversal phase when fewer lanes than this still traverse ...
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
+#define PT_W_INNER 2           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
+#define PT_W_LEAF 3            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
 #define PT_MAX_BATCH 8         // frames per launch
 
 enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
@@ -51,6 +53,7 @@ struct PathsArgs {
     uint32_t pixels;                // width * height
     int cache_recs;                 // records actually staged (<= PT_CACHE)
     int min_trav, min_service;      // phase-switch thresholds (lanes)
+    int w_inner, w_leaf;            // an inner step runs when w_inner * (lanes at inner nodes) >= w_leaf * (lanes at leaves)
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
     size_t spill_stride;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                 const bool serviceable = exhausted ? __builtin_amdgcn_ballot_w64(state == ST_DONE) != 0ull : true;
                 if (serviceable) break;
             }
-            if (ni >= nl) {
+            if (ni * (uint32_t)a.w_inner >= nl * (uint32_t)a.w_leaf) {
                 if (want_inner) {
                     DIAG(0, 1);
                     DIAG(1, 1);
