@@ -1,24 +1,27 @@
 // Persistent path kernel: the default pipeline of the render path on MI355X.
 //
-// One launch renders a BATCH of frames.  The grid is one 1024-thread workgroup per CU; every wave is an
-// independent worker that keeps its 64 lanes busy with paths drawn from a pool of (frame, 8x8 pixel tile)
+// One launch renders a BATCH of frames.  The grid is two 768-thread workgroups per CU (24 waves, 6 per SIMD); every
+// wave is an independent worker that keeps its 64 lanes busy with paths drawn from a pool of (frame, 8x8 pixel tile)
 // items, so that lanes whose path has ended (60 % of primary rays leave the scene at once) do not idle while
 // their neighbours traverse.  Each wave alternates two phases, each of which runs one kind of code on as many
 // lanes as possible:
 //
-//   service   shade the lanes whose traversal has finished (bounce + Russian roulette, or sky and sample
-//             store), refill empty lanes with new primary rays (wave ballot + mbcnt prefix over the empty
-//             lanes, tiles handed out by a workgroup-local LDS counter -- no global atomics at all), and run
-//             the root-box test of every new ray;
-//   traverse  ordered BVH traversal, itself split in an inner-node loop and a leaf loop, until too few lanes
-//             are still traversing.
+//   service   shade the lanes whose traversal has finished (bounce + Russian roulette, or the sample store),
+//             refill empty lanes with new primary rays (wave ballot + mbcnt prefix over the empty lanes, tiles
+//             handed out by a workgroup-local LDS counter -- no global atomics at all), and run the root-box
+//             test of every new ray;
+//   traverse  ordered BVH traversal; every iteration runs ONE kind of step (inner-node visit or triangle test),
+//             chosen by a weighted vote of the lanes, until too few lanes are still traversing.
 //
-// Memory placement (LDS is 160 KiB per CU and one workgroup owns all of it):
-//   traversal stacks   12 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict:
-//                      96 KiB; deeper entries (rare) spill to HBM, coalesced across the wave
-//   top of the BVH     the first PT_CACHE inner-node records (breadth-first, ~10 levels of an 80K-triangle
-//                      tree) are staged in LDS once per workgroup: 62.5 KiB.  Quads of a record are XOR-
-//                      swizzled so that lanes reading different records spread over all 16-byte bank slots
+// The kernel is bound by VALU issue (98 % of all issue slots on dragon80k), so what matters is the number of vector
+// instructions per step and how many lanes each of them serves.
+//
+// Memory placement (LDS is 160 KiB per CU, 80 KiB per workgroup):
+//   traversal stacks   8 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict: 48 KiB;
+//                      deeper entries (rare) spill to HBM, coalesced across the wave
+//   top of the BVH     the first PT_CACHE inner-node records (breadth-first, ~9 levels) are staged in LDS once
+//                      per workgroup: 32 KiB.  Quads of a record are XOR-swizzled so that lanes reading different
+//                      records spread over all 16-byte bank slots
 //   everything else    registers: ray, throughput, RNG state, pixel, bounce index, traversal cursor
 //
 // A finished path stores (throughput.rgb, dir.y) into a staging array [frame][pixel]; k_accumulate evaluates the
