@@ -137,7 +137,8 @@ def main() -> int:
         the library is free to render the frames of a call concurrently."""
         if tiles:  # every rank renders the same frames, restricted to its band; bands are disjoint, so the
             # closing sum-reduce of the (elsewhere zero) buffers is the gather
-            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=first_step, frames=nsteps, flags=flags, band=(rank, world))
+            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=first_step, frames=nsteps, flags=flags, band=(rank, world),
+                                interleaved=True)
         else:
             base, stride, n = partition.rank_frames(rank, world, first_step, nsteps)
             p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=base, frames=n, frame_stride=stride, flags=flags)
@@ -316,13 +317,14 @@ def run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank,
             _, build_ms = ctx.refit_scene_device(d_v.data_ptr())
         else:
             _, build_ms = ctx.rebuild_scene_device(d_v.data_ptr())
-        ctx.render_device(cam, pkg.make_params(W, H, frames=1, flags=flags | extra_flags, band=band), frame.data_ptr())
+        ctx.render_device(cam, pkg.make_params(W, H, frames=1, flags=flags | extra_flags, band=band, interleaved=True), frame.data_ptr())
         if dist is not None:
             dist.reduce(frame, dst=0)
             if rank == 0 and world > 1:  # keep only this rank's band for the next step's reduce
-                r0, r1 = partition.band_rows(rank, world, H)
-                frame[:r0].zero_()
-                frame[r1:].zero_()
+                keep = torch.zeros(H, dtype=torch.bool, device=dev)
+                for r0, r1 in partition.band_row_ranges(rank, world, H, True):
+                    keep[r0:r1] = True
+                frame[~keep] = 0.0
         return build_ms
 
     def barrier():
@@ -354,7 +356,7 @@ def run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank,
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for _ in range(8):
-        ctx.render_device(cam, pkg.make_params(W, H, frames=1, flags=flags, band=band), frame.data_ptr())
+        ctx.render_device(cam, pkg.make_params(W, H, frames=1, flags=flags, band=band, interleaved=True), frame.data_ptr())
     torch.cuda.synchronize(dev)
     render_ms = (time.perf_counter() - t1) / 8 * 1e3
     if rank == 0:

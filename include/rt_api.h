@@ -93,10 +93,13 @@ typedef struct rt_params {
     uint32_t frame_stride;    /* frameCount step between frames; 0 or 1 = consecutive */
     uint32_t flags;           /* RT_FLAG_* */
     uint32_t band;            /* 0 = whole image; (index << 16) | count = render only horizontal band `index` of
-                                 `count` (image-tile partition across GPUs).  Bands are runs of 8-pixel tile rows:
-                                 band i covers tile rows [i*R/count, (i+1)*R/count), R = ceil(height/8); pixels
-                                 outside the band are neither read nor written; seeds use global pixel indices, so
-                                 the union of the bands is bit-identical to the whole image.  Default pipeline only. */
+                                 `count` (the image-tile partition over GPUs, count <= 32767).  Contiguous bands:
+                                 band i covers tile rows [i*R/count, (i+1)*R/count), R = ceil(height/8).  With
+                                 RT_BAND_INTERLEAVED or-ed in, band i is the 16-pixel-row stripes number i, i+count,
+                                 i+2*count, ... (bottom to top), which spreads an object in the middle of the image over
+                                 all bands.  Pixels outside the band are neither read nor written; seeds use global pixel
+                                 indices, so the union of the bands is bit-identical to the whole image.  Default
+                                 pipeline only. */
 } rt_params;
 
 typedef struct rt_context rt_context;
@@ -105,6 +108,7 @@ typedef struct rt_context rt_context;
  * [0] box tests (numBoxTests, raytrace.glsl:114)   [1] triangle tests (numTriangleTests, :80)
  * [2] rays = calls of getHitInfo (:245)            [3] rays that hit a triangle
  * [4] node pops that reached the node fetch (:154) [5] pixel samples (paths) */
+#define RT_BAND_INTERLEAVED 0x8000u /* rt_params.band: stripes of 16 pixel rows dealt round-robin to the bands */
 #define RT_NUM_COUNTERS 6
 
 /* ---- life cycle -------------------------------------------------------------------- */

@@ -25,6 +25,7 @@ RT_FLAG_SUM = 0x2
 RT_FLAG_MEGAKERNEL = 0x4
 RT_FLAG_COUNTERS = 0x8
 RT_FLAG_WAVEFRONT = 0x10
+RT_BAND_INTERLEAVED = 0x8000
 RT_NUM_COUNTERS = 6
 RT_NUM_KERNEL_CLASSES = 7
 KERNEL_CLASS_NAMES = ["generate", "extend", "shade", "tail", "accumulate", "mega", "paths"]
@@ -346,9 +347,10 @@ def make_camera(pos=(0.0, 0.0, -2.0), pitch=0.0, yaw=0.0, fov_deg=90.0, viewport
 
 
 def make_params(width=1920, height=1080, rays_per_pixel=1, ray_bounces=100, render_mode=1, frame_base=0, frames=1,
-                frame_stride=1, flags=0, band=None) -> RtParams:
-    """band = (index, count) restricts the render to one horizontal band of the image (tile partition)."""
-    b = 0 if band is None else ((int(band[0]) << 16) | int(band[1]))
+                frame_stride=1, flags=0, band=None, interleaved=False) -> RtParams:
+    """band = (index, count) restricts the render to one horizontal band of the image (tile partition); with
+    interleaved=True the band is every count-th stripe of 16 pixel rows instead of one contiguous range."""
+    b = 0 if band is None else ((int(band[0]) << 16) | int(band[1]) | (RT_BAND_INTERLEAVED if interleaved else 0))
     return RtParams(width, height, rays_per_pixel, ray_bounces, render_mode, frame_base, frames, frame_stride, flags, b)
 
 

@@ -544,7 +544,7 @@ static int check_render_args(rt_context* c, const rt_camera* cam, const rt_param
     if (p->render_mode < RT_MODE_RENDER || p->render_mode > RT_MODE_REFLECTIONS)
         return fail(c, RT_EINVAL, "render_mode must be 1..4");
     if (p->band) {
-        const uint32_t idx = p->band >> 16, cnt = p->band & 0xffffu;
+        const uint32_t idx = p->band >> 16, cnt = p->band & 0x7fffu;
         if (cnt == 0 || idx >= cnt) return fail(c, RT_EINVAL, "band index %u out of range for %u bands", idx, cnt);
         if ((p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) || p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 ||
             p->ray_bounces == 0)
@@ -590,20 +590,51 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     return RT_OK;
 }
 
-// Tile rows [ty0, ty1) and pixel range of the band selected by params->band (whole image for 0).
-static void band_rows(const rt_params* p, int* ty0, int* ty1, uint32_t* first_pixel, uint32_t* num_pixels) {
-    const int R = (p->height + 7) / 8;
-    int t0 = 0, t1 = R;
-    if (p->band) {
-        const int idx = (int)(p->band >> 16), cnt = (int)(p->band & 0xffffu);
-        t0 = (int)((int64_t)idx * R / cnt);
-        t1 = (int)((int64_t)(idx + 1) * R / cnt);
+// The rows of the band selected by params->band (the whole image for 0).
+//   contiguous band i of n: tile rows [i*R/n, (i+1)*R/n), R = ceil(height / 8)
+//   interleaved band i of n (RT_BAND_INTERLEAVED): the stripes of PT_STRIPE_TILES tile rows number i, i+n, i+2n, ...
+struct BandLayout {
+    int tile_y0 = 0, tile_rows = 0, stripe_period = 0;  // kernel view (tile rows)
+    BandPixels px{};                                    // accumulate view (pixel rows)
+    // pixel-row ranges [first, first + count) that make up the band, for transfers and clears
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+};
+
+static BandLayout band_layout(const rt_params* p) {
+    BandLayout b;
+    const int H = p->height, W = p->width, R = (H + 7) / 8;
+    const int idx = p->band ? (int)(p->band >> 16) : 0;
+    const int cnt = p->band ? (int)(p->band & 0x7fffu) : 1;
+    const bool inter = p->band && (p->band & RT_BAND_INTERLEAVED) && cnt > 1;
+    b.px.width = (uint32_t)W;
+    if (!inter) {
+        const int t0 = (int)((int64_t)idx * R / cnt), t1 = (int)((int64_t)(idx + 1) * R / cnt);
+        const int r0 = t0 * 8 < H ? t0 * 8 : H, r1 = t1 * 8 < H ? t1 * 8 : H;
+        b.tile_y0 = t0;
+        b.tile_rows = t1 - t0;
+        b.px.row0 = (uint32_t)r0;
+        b.px.num_pixels = (uint32_t)(r1 - r0) * (uint32_t)W;
+        if (r1 > r0) b.ranges.push_back({(uint32_t)r0, (uint32_t)(r1 - r0)});
+        return b;
     }
-    const int r0 = t0 * 8 < p->height ? t0 * 8 : p->height, r1 = t1 * 8 < p->height ? t1 * 8 : p->height;
-    *ty0 = t0;
-    *ty1 = t1;
-    *first_pixel = (uint32_t)r0 * (uint32_t)p->width;
-    *num_pixels = (uint32_t)(r1 - r0) * (uint32_t)p->width;
+    const int U = PT_STRIPE_TILES;
+    b.tile_y0 = idx * U;
+    b.stripe_period = U * cnt;
+    b.px.row0 = (uint32_t)(idx * U * 8);
+    b.px.stripe_rows = (uint32_t)(U * 8);
+    b.px.period_rows = (uint32_t)(U * 8 * cnt);
+    uint32_t rows = 0;
+    for (int t = idx * U; t < R; t += U * cnt) {  // first tile row of each stripe
+        const int te = t + U < R ? t + U : R;
+        const int r0 = t * 8, r1 = te * 8 < H ? te * 8 : H;
+        b.tile_rows += te - t;
+        if (r1 > r0) {
+            b.ranges.push_back({(uint32_t)r0, (uint32_t)(r1 - r0)});
+            rows += (uint32_t)(r1 - r0);
+        }
+    }
+    b.px.num_pixels = rows * (uint32_t)W;
+    return b;
 }
 
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
@@ -621,12 +652,11 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     a.frame_stride = stride;
     a.num_frames = nframes;
     a.bounces = p->ray_bounces;
-    int ty0, ty1;
-    uint32_t first_pixel, num_pixels;
-    band_rows(p, &ty0, &ty1, &first_pixel, &num_pixels);
+    const BandLayout bl = band_layout(p);
     a.tiles_x = (p->width + 7) / 8;
-    a.tile_y0 = ty0;
-    a.tiles_per_frame = a.tiles_x * (ty1 - ty0);
+    a.tile_y0 = bl.tile_y0;
+    a.stripe_period = bl.stripe_period;
+    a.tiles_per_frame = a.tiles_x * bl.tile_rows;
     a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
     a.pixels = (uint32_t)pixels;
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
@@ -656,9 +686,9 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
         uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
-        if (num_pixels)
-            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((num_pixels + 255) / 256)), dim3(256), 0, c->stream,
-                               (const float4*)c->d_samples, nframes, (uint32_t)pixels, first_pixel, num_pixels, frame_base, stride,
+        if (bl.px.num_pixels)
+            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((bl.px.num_pixels + 255) / 256)), dim3(256), 0, c->stream,
+                               (const float4*)c->d_samples, nframes, (uint32_t)pixels, bl.px, frame_base, stride,
                                sum ? 1u : 0u, read_prev, prev, out);
     }
     HIPCHK(c, hipGetLastError());
@@ -716,8 +746,11 @@ static int launch_paths2_batch(rt_context* c, const DCamera& dc, const rt_params
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
         uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
+        BandPixels whole{};
+        whole.width = (uint32_t)p->width;
+        whole.num_pixels = (uint32_t)pixels;
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, c->stream,
-                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, 0u, (uint32_t)pixels, frame_base, stride,
+                           (const float4*)c->d_samples, nframes, (uint32_t)pixels, whole, frame_base, stride,
                            sum ? 1u : 0u, read_prev, prev, out);
     }
     HIPCHK(c, hipGetLastError());
@@ -1356,11 +1389,9 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     if (!d_accum) return fail(c, RT_EINVAL, "d_accum is NULL");
     uint32_t stride = p->frame_stride ? p->frame_stride : 1u;
     if ((p->flags & RT_FLAG_SUM) && p->frame_base == 0) {
-        int ty0, ty1;
-        uint32_t first_pixel, num_pixels;
-        band_rows(p, &ty0, &ty1, &first_pixel, &num_pixels);  // only the band that will be rendered is cleared
-        if (num_pixels)
-            HIPCHK(c, hipMemsetAsync(d_accum + (size_t)first_pixel * 4, 0, (size_t)num_pixels * 4 * sizeof(float), c->stream));
+        const BandLayout bl = band_layout(p);  // only the band that will be rendered is cleared
+        for (const auto& r : bl.ranges)
+            HIPCHK(c, hipMemsetAsync(d_accum + (size_t)r.first * p->width * 4, 0, (size_t)r.second * p->width * 4 * sizeof(float), c->stream));
     }
     const bool per_frame = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) != 0 ||
                            p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 || p->ray_bounces == 0;
@@ -1396,21 +1427,21 @@ int rt_render(rt_context* c, const rt_camera* cam, const rt_params* p, float* ou
         c->frame_pixels = pixels;
     }
     // only the band being rendered travels; the rest of the caller's buffer is left alone
-    int ty0, ty1;
-    uint32_t first_pixel, num_pixels;
-    band_rows(p, &ty0, &ty1, &first_pixel, &num_pixels);
-    float4* d_band = c->d_frame + first_pixel;
-    float* h_band = out_rgba + (size_t)first_pixel * 4;
-    if (num_pixels) {
+    const BandLayout bl = band_layout(p);
+    for (const auto& r : bl.ranges) {
+        float4* d_rows = c->d_frame + (size_t)r.first * p->width;
+        const float* h_rows = out_rgba + (size_t)r.first * p->width * 4;
+        const size_t bytes = (size_t)r.second * p->width * sizeof(float4);
         if (p->frame_base != 0)
-            HIPCHK(c, hipMemcpyAsync(d_band, h_band, (size_t)num_pixels * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_rows, h_rows, bytes, hipMemcpyHostToDevice, c->stream));
         else
-            HIPCHK(c, hipMemsetAsync(d_band, 0, (size_t)num_pixels * sizeof(float4), c->stream));
+            HIPCHK(c, hipMemsetAsync(d_rows, 0, bytes, c->stream));
     }
     rc = rt_render_device(c, cam, p, (float*)c->d_frame);
     if (rc != RT_OK) return rc;
-    if (num_pixels)
-        HIPCHK(c, hipMemcpyAsync(h_band, d_band, (size_t)num_pixels * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    for (const auto& r : bl.ranges)
+        HIPCHK(c, hipMemcpyAsync(out_rgba + (size_t)r.first * p->width * 4, c->d_frame + (size_t)r.first * p->width,
+                                 (size_t)r.second * p->width * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -44,6 +44,7 @@
 #define PT_W_INNER 2           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
 #define PT_W_LEAF 3            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
 #define PT_MAX_BATCH 8         // frames per launch
+#define PT_STRIPE_TILES 2      // interleaved bands: a stripe is 2 tile rows = 16 pixel rows
 
 enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
 
@@ -51,7 +52,8 @@ struct PathsArgs {
     uint32_t frame_base, frame_stride, num_frames;
     uint32_t bounces;
     int tiles_x, tiles_per_frame;   // 8x8 pixel tiles (of the band being rendered)
-    int tile_y0;                    // first tile row of the band
+    int tile_y0;                    // first tile row of the band (contiguous band) or of its first stripe (interleaved)
+    int stripe_period;              // 0: contiguous band; else tile rows between two stripes of the band (PT_STRIPE_TILES * bands)
     uint32_t total_tiles;           // num_frames * tiles_per_frame
     uint32_t pixels;                // width * height
     int cache_recs;                 // records actually staged (<= PT_CACHE)
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         uint32_t f = tile_g / (uint32_t)a.tiles_per_frame;
                         int t = (int)(tile_g - f * (uint32_t)a.tiles_per_frame);
                         int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                        int gx = tx * 8 + (l & 7), gy = (ty + a.tile_y0) * 8 + (l >> 3);
+                        // tile row of the band -> tile row of the image
+                        const int gty = a.stripe_period ? (ty / PT_STRIPE_TILES) * a.stripe_period + (ty % PT_STRIPE_TILES) + a.tile_y0
+                                                        : ty + a.tile_y0;
+                        int gx = tx * 8 + (l & 7), gy = gty * 8 + (l >> 3);
                         if (gx < cam.width && gy < cam.height) {
                             primary_ray(cam, gx, gy, p.o, p.d, p.inv);
                             p.seed = pixel_seed(cam, gx, gy, a.frame_base + f * a.frame_stride);
@@ -369,13 +374,23 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
 
 // Folds the staged samples of one batch into the framebuffer, frame by frame in order:
 // final = (acc*frameCount + colour) / (frameCount + 1)   (raytrace.glsl:296), or acc + colour in SUM mode.
-__global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint32_t num_frames, uint32_t pixels,
-                                                    uint32_t first_pixel, uint32_t num_pixels, uint32_t frame_base,
-                                                    uint32_t frame_stride, uint32_t sum_mode, uint32_t read_prev,
-                                                    const float4* prev, float4* out) {
+// The pixels of a band, numbered 0 .. num_pixels-1 row by row: rows [row0, ...) for a contiguous band; for an
+// interleaved band stripes of stripe_rows rows, period_rows apart, starting at row0.
+struct BandPixels {
+    uint32_t width, row0, stripe_rows, period_rows, num_pixels;
+};
+
+__global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint32_t num_frames, uint32_t pixels, BandPixels bp,
+                                                    uint32_t frame_base, uint32_t frame_stride, uint32_t sum_mode,
+                                                    uint32_t read_prev, const float4* prev, float4* out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= num_pixels) return;
-    i += first_pixel;
+    if (i >= bp.num_pixels) return;
+    if (bp.period_rows) {
+        const uint32_t lr = i / bp.width, x = i - lr * bp.width;
+        i = ((lr / bp.stripe_rows) * bp.period_rows + lr % bp.stripe_rows + bp.row0) * bp.width + x;
+    } else {
+        i += bp.row0 * bp.width;
+    }
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (read_prev) acc = prev[i];
     for (uint32_t j = 0; j < num_frames; j++) {

@@ -33,3 +33,20 @@ def band_rows(index: int, count: int, height: int):
     R = (height + 7) // 8
     t0, t1 = index * R // count, (index + 1) * R // count
     return min(t0 * 8, height), min(t1 * 8, height)
+
+
+def band_row_ranges(index: int, count: int, height: int, interleaved: bool = False):
+    """Pixel-row ranges [(r0, r1), ...] of band `index` of `count`.  Contiguous: the one range of band_rows().
+    Interleaved: the stripes of 16 pixel rows number index, index + count, index + 2*count, ... -- an object in the
+    middle of the image is then shared by all bands instead of landing on the middle ones."""
+    if not interleaved or count == 1:
+        r0, r1 = band_rows(index, count, height)
+        return [(r0, r1)] if r1 > r0 else []
+    if not (0 <= index < count):
+        raise ValueError("bad band")
+    out = []
+    r = index * 16
+    while r < height:
+        out.append((r, min(r + 16, height)))
+        r += 16 * count
+    return out

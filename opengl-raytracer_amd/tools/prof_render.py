@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fix-invdir", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="time rt_primary_hits instead of full frames")
     ap.add_argument("--counters", action="store_true", help="render with RT_FLAG_COUNTERS and print the work counters")
+    ap.add_argument("--bands", type=int, default=0, help="time every band of an N-way tile partition on this one GPU")
     a = ap.parse_args()
     pkg = entry.load_package()
     obj, pos = SCENES[a.scene]
@@ -53,6 +54,22 @@ def main():
     if a.counters:
         flags |= pkg.RT_FLAG_COUNTERS
     img = np.zeros((a.height, a.width, 4), dtype=np.float32)
+    if a.bands:
+        # what an N-GPU tile partition would see: the slowest band sets the frame time
+        for inter in (False, True):
+            ms = []
+            for g in range(a.bands):
+                p = pkg.make_params(a.width, a.height, frames=a.frames, flags=flags, band=(g, a.bands), interleaved=inter)
+                best = 1e9
+                for _ in range(4):  # first call warms up, the best of the others counts
+                    t0 = time.perf_counter()
+                    ctx.render(cam, p, img)
+                    best = min(best, (time.perf_counter() - t0) / a.frames * 1e3)
+                ms.append(best)
+            print(f"{a.bands} {'interleaved' if inter else 'contiguous'} bands, ms per frame per band: "
+                  + " ".join(f"{x:.3f}" for x in ms) + f" | max {max(ms):.3f} mean {sum(ms) / len(ms):.3f} balance {sum(ms) / len(ms) / max(ms):.2f}")
+        ctx.close()
+        return
     ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags), img)
     t0 = time.perf_counter()
     ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.frames, flags=flags), img)

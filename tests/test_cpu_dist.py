@@ -40,3 +40,11 @@ def test_band_rows_partition_the_image(pkg):
             assert rows[0][0] == 0 and rows[-1][1] == height
             assert all(rows[i][1] == rows[i + 1][0] for i in range(count - 1))
             assert all(r0 % 8 == 0 for r0, _ in rows if r0 < height)
+            for interleaved in (False, True):
+                covered = [0] * height
+                for i in range(count):
+                    for r0, r1 in partition.band_row_ranges(i, count, height, interleaved):
+                        assert 0 <= r0 < r1 <= height
+                        for r in range(r0, r1):
+                            covered[r] += 1
+                assert all(c == 1 for c in covered)

@@ -361,8 +361,9 @@ def test_two_contexts_are_independent(pkg, oracle, scenes):
     b.close()
 
 
-@pytest.mark.parametrize("size,bands", [((333, 217), 3), ((640, 360), 8), ((64, 20), 5)])
-def test_band_partition_union_equals_whole_image(pkg, oracle, gpu_ctx, scenes, size, bands):
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("size,bands", [((333, 217), 3), ((640, 360), 8), ((64, 20), 5), ((200, 1080 // 4), 2)])
+def test_band_partition_union_equals_whole_image(pkg, oracle, gpu_ctx, scenes, size, bands, interleaved):
     """Image-tile partition (BASELINE configs[4]): each band rendered by its own call, into the rows
     partition.band_rows() names and nowhere else; the union is bit-identical to the whole image and to the oracle."""
     from opengl_raytracer_amd import partition
@@ -379,17 +380,19 @@ def test_band_partition_union_equals_whole_image(pkg, oracle, gpu_ctx, scenes, s
     for g in range(bands):
         buf = np.full((H, W, 4), sentinel, dtype=np.float32)
         # frame_base 0 ignores the buffer's content inside the band; outside the band it must stay untouched
-        out = gpu_ctx.render(cam, pkg.make_params(W, H, frames=3, band=(g, bands)), buf)
-        r0, r1 = partition.band_rows(g, bands, H)
-        covered[r0:r1] += 1
-        assert np.all(out[:r0] == sentinel) and np.all(out[r1:] == sentinel)
-        union[r0:r1] = out[r0:r1]
+        out = gpu_ctx.render(cam, pkg.make_params(W, H, frames=3, band=(g, bands), interleaved=interleaved), buf)
+        mine = np.zeros(H, dtype=bool)
+        for r0, r1 in partition.band_row_ranges(g, bands, H, interleaved):
+            mine[r0:r1] = True
+        covered += mine
+        assert np.all(out[~mine] == sentinel)
+        union[mine] = out[mine]
     assert np.all(covered == 1)
     assert np.array_equal(bits(union), bits(whole))
     # SUM mode over bands into ONE buffer
     acc = np.zeros((H, W, 4), dtype=np.float32)
     for g in range(bands):
-        acc = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2, flags=pkg.RT_FLAG_SUM, band=(g, bands)), acc)
+        acc = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2, flags=pkg.RT_FLAG_SUM, band=(g, bands), interleaved=interleaved), acc)
     want_sum = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2, flags=pkg.RT_FLAG_SUM))
     assert np.array_equal(bits(acc), bits(want_sum))
 
