@@ -31,6 +31,18 @@ def test_two_rank_sum_reduce_matches_sequential_mean(tmp_path):
     assert float(res["rays"]) == float(res["rays_seq"])   # every frame rendered exactly once
 
 
+def test_two_rank_tile_partition_gathers_the_exact_image(tmp_path):
+    out = tmp_path / "tiles.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29643", os.path.join(ROOT, "tests", "dist_worker.py"), "3", str(out), "tiles"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = np.load(out)
+    assert bool(res["same"])                               # bands are disjoint: the gathered image is bit-exact
+    assert float(res["rays"]) == float(res["rays_seq"])
+
+
 def test_band_rows_partition_the_image(pkg):
     from opengl_raytracer_amd import partition
 
