@@ -1105,9 +1105,9 @@ int rt_counters(rt_context* c, uint64_t out[RT_NUM_COUNTERS]) {
     {
         unsigned long long d[12];
         (void)hipMemcpy(d, c->d_counters + 8, sizeof d, hipMemcpyDeviceToHost);
-        fprintf(stderr, "PT_DIAG inner iters %llu lanes/iter %.2f | leaf phases %llu lanes/phase %.2f | service iters %llu lanes/iter %.2f | tri iters %llu lanes/iter %.2f\n",
-                d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[2], d[2] ? (double)d[3] / d[2] : 0.0, d[4], d[4] ? (double)d[5] / d[4] : 0.0,
-                d[6], d[6] ? (double)d[7] / d[6] : 0.0);
+        fprintf(stderr, "PT_DIAG inner iters %llu lanes/iter %.2f (waiting at a leaf %.2f, finished %.2f, empty %.2f) | service iters %llu lanes/iter %.2f | tri iters %llu lanes/iter %.2f\n",
+                d[0], d[0] ? (double)d[1] / d[0] : 0.0, d[0] ? (double)d[3] / d[0] : 0.0, d[0] ? (double)d[9] / d[0] : 0.0,
+                d[0] ? (double)d[11] / d[0] : 0.0, d[4], d[4] ? (double)d[5] / d[4] : 0.0, d[6], d[6] ? (double)d[7] / d[6] : 0.0);
     }
 #endif
     return RT_OK;

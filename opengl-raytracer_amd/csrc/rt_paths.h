@@ -150,7 +150,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     Counters cn = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
 #ifdef PT_DIAG
-    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 // iteration counters (even k): only the first active lane counts; lane sums (odd k): every active lane adds 1
 #define DIAG(k_, v_) dg[k_] += ((k_) & 1) ? 1ull : (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u ? 1ull : 0ull)
 #else
@@ -275,6 +275,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                 if (serviceable) break;
             }
             if (ni * (uint32_t)a.w_inner >= nl * (uint32_t)a.w_leaf) {
+                if (want_leaf) { DIAG(3, 1); }
+                if (state == ST_DONE) { DIAG(9, 1); }
+                if (state == ST_NEED) { DIAG(11, 1); }
                 if (want_inner) {
                     DIAG(0, 1);
                     DIAG(1, 1);
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     if (COUNT && a.counters) flush_counters6(cn, paths, a.counters);
 #ifdef PT_DIAG
     if (a.counters)
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 12; k++) {
             unsigned long long x = dg[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((tid & 63) == 0) atomicAdd(&a.counters[8 + k], x);
