@@ -256,6 +256,13 @@ static DCamera make_dcamera(const rt_camera* cam, int width, int height) {
 }
 
 // Buffers of the persistent path kernel: sample staging for one batch and the stack spill area.
+// Frames rendered by one launch of the path kernel: PT_MAX_BATCH, fewer for very large images so that the staged
+// samples (16 bytes per pixel and frame) stay within 2 GiB.
+static uint32_t paths_batch(size_t pixels) {
+    const size_t fit = ((size_t)2 << 30) / (pixels * sizeof(float4));
+    return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
+}
+
 static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
     if (pixels <= c->samples_pixels && want_spill <= c->pspill_entries) return RT_OK;
@@ -263,7 +270,7 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     if (pixels > c->samples_pixels) {
         dfree(c->d_samples);
         c->samples_pixels = 0;
-        HIPCHK(c, hipMalloc(&c->d_samples, (size_t)PT_MAX_BATCH * pixels * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_samples, (size_t)paths_batch(pixels) * pixels * sizeof(float4)));
         c->samples_pixels = pixels;
     }
     if (want_spill > c->pspill_entries) {
@@ -1026,8 +1033,9 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     }
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
-    for (uint32_t f = 0; f < p->frames; f += PT_MAX_BATCH) {
-        uint32_t n = p->frames - f < PT_MAX_BATCH ? p->frames - f : PT_MAX_BATCH;
+    const uint32_t batch = paths_batch((size_t)p->width * p->height);
+    for (uint32_t f = 0; f < p->frames; f += batch) {
+        uint32_t n = p->frames - f < batch ? p->frames - f : batch;
         rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum);
         if (rc != RT_OK) return rc;
     }

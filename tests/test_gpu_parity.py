@@ -403,3 +403,23 @@ def test_band_argument_errors(pkg, gpu_ctx, scenes):
     for bad in (dict(band=(3, 3)), dict(band=(0, 2), flags=pkg.RT_FLAG_MEGAKERNEL), dict(band=(0, 2), rays_per_pixel=2)):
         with pytest.raises(RuntimeError):
             gpu_ctx.render(cam, pkg.make_params(64, 64, **bad))
+
+
+def test_large_image_uses_smaller_batches(pkg, gpu_ctx, scenes):
+    """At 8192x4096 the staged samples of 8 frames would take 4.3 GB; the library renders fewer frames per launch
+    (2 GiB of staging at most).  Rendering 5 frames in one call must equal five single-frame dispatches bit for bit."""
+    gpu_ctx.upload_scene(scenes("teapot"))
+    cam = pkg.make_camera()
+    W, H = 8192, 4096
+    nbytes = W * H * 16
+    a, b = pkg.DeviceBuffer(nbytes), pkg.DeviceBuffer(nbytes)
+    gpu_ctx.render_device(cam, pkg.make_params(W, H, frames=5), a.ptr)
+    for f in range(5):
+        gpu_ctx.raytrace_frame(cam, pkg.make_params(W, H), f, b.ptr, b.ptr)
+    gpu_ctx.synchronize()
+    img_a = a.to_array((H, W, 4), np.float32)
+    img_b = b.to_array((H, W, 4), np.float32)
+    a.free()
+    b.free()
+    assert np.array_equal(bits(img_a), bits(img_b))
+    assert img_a[..., 3].min() == 2.0 and img_a[..., :3].max() <= 1.0 and img_a[..., :3].min() >= 0.0
