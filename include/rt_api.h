@@ -60,6 +60,9 @@ extern "C" {
  *            (raytrace.glsl:155-168); node 0 is the root
  *   triv0/1/2  num_tris x 4 floats (xyz + pad), the three vertices of each triangle
  *   colours  num_tris x 4 floats (rgb + pad), the per-triangle albedo of raytrace.cpp:44-52
+ *   links    optional (may be NULL): num_nodes x 2 int32 (a, b) that replace the float-encoded a, b of nodes.  A
+ *            float holds integers exactly only up to 2^24, so the reference's own encoding (bvh.cpp:177-187) cannot
+ *            address larger trees; scenes with more than 2^24 nodes or triangles must pass links.
  * All host pointers; rt_upload_scene copies. */
 typedef struct rt_scene {
     int32_t num_nodes;
@@ -69,6 +72,7 @@ typedef struct rt_scene {
     const float* triv1;
     const float* triv2;
     const float* colours;
+    const int32_t* links;
 } rt_scene;
 
 /* Per-frame uniforms cameraPos / cameraRotation (raytrace.cpp:80-83) and the static
@@ -157,6 +161,9 @@ int rt_refit_scene_device(rt_context* ctx, const float* d_vertices);
  * call once with only the two counts to size the arrays. */
 int rt_get_built_scene(rt_context* ctx, int32_t* num_nodes, int32_t* num_tris, float* nodes, float* triv0, float* triv1,
                        float* triv2, float* colours, int32_t* tri_src, float* build_ms);
+/* The exact integer (a, b) of every node of the device-built scene (num_nodes x 2 int32), i.e. rt_scene.links: the
+ * float-encoded ids in `nodes` are inexact beyond 2^24. */
+int rt_get_built_links(rt_context* ctx, int32_t* links);
 
 /* ---- rendering --------------------------------------------------------------------- */
 /* One dispatch of the reference: raytrace(cameraPos, cameraRotation, renderMode, frameCount,

@@ -66,6 +66,7 @@ class RtScene(C.Structure):
         ("triv1", c_float_p),
         ("triv2", c_float_p),
         ("colours", c_float_p),
+        ("links", c_int32_p),
     ]
 
 
@@ -118,6 +119,7 @@ HIP_SYMBOLS = [
     "rt_rebuild_scene_device",
     "rt_refit_scene_device",
     "rt_get_built_scene",
+    "rt_get_built_links",
     "rt_raytrace_frame",
     "rt_render_device",
     "rt_render",
@@ -180,6 +182,7 @@ def load_hip() -> C.CDLL:
         lib.rt_upload_scene.argtypes = [vp, C.POINTER(RtScene)]
         lib.rt_get_normals.argtypes = [vp, c_float_p]
         lib.rt_build_scene_device.argtypes = [vp, c_float_p, C.c_int32, c_uint32_p, C.c_int32, c_float_p]
+        lib.rt_get_built_links.argtypes = [vp, c_int32_p]
         lib.rt_rebuild_scene_device.argtypes = [vp, vp]
         lib.rt_refit_scene_device.argtypes = [vp, vp]
         lib.rt_get_built_scene.argtypes = [vp, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
@@ -256,7 +259,7 @@ def fptr(a: np.ndarray):
 class Scene:
     """A scene in the reference's upload layout, as numpy arrays (host memory)."""
 
-    def __init__(self, nodes, triv0, triv1, triv2, colours, tri_src=None, stats=None):
+    def __init__(self, nodes, triv0, triv1, triv2, colours, tri_src=None, stats=None, links=None):
         self.nodes = np.ascontiguousarray(nodes, dtype=np.float32).reshape(-1, 12)
         self.triv0 = np.ascontiguousarray(triv0, dtype=np.float32).reshape(-1, 4)
         self.triv1 = np.ascontiguousarray(triv1, dtype=np.float32).reshape(-1, 4)
@@ -264,6 +267,8 @@ class Scene:
         self.colours = np.ascontiguousarray(colours, dtype=np.float32).reshape(-1, 4)
         self.tri_src = tri_src
         self.stats = stats or {}
+        # optional exact (a, b) per node, rt_scene.links: required beyond 2^24 nodes, where float ids are inexact
+        self.links = None if links is None else np.ascontiguousarray(links, dtype=np.int32).reshape(-1, 2)
 
     @property
     def num_tris(self):
@@ -276,7 +281,7 @@ class Scene:
     def as_rt_scene(self) -> RtScene:
         return RtScene(
             self.num_nodes, self.num_tris, fptr(self.nodes), fptr(self.triv0), fptr(self.triv1), fptr(self.triv2),
-            fptr(self.colours)
+            fptr(self.colours), None if self.links is None else self.links.ctypes.data_as(c_int32_p)
         )
 
 
@@ -424,7 +429,9 @@ class RenderContext:
         src = np.empty(t.value, dtype=np.int32)
         self._check(self.lib.rt_get_built_scene(self.ctx, None, None, fptr(nodes), fptr(v0), fptr(v1), fptr(v2), fptr(cc),
                                                 src.ctypes.data_as(c_int32_p), None), "rt_get_built_scene")
-        return Scene(nodes, v0, v1, v2, cc, src, {"build_ms": ms.value}), ms.value
+        links = np.empty((n.value, 2), dtype=np.int32)
+        self._check(self.lib.rt_get_built_links(self.ctx, links.ctypes.data_as(c_int32_p)), "rt_get_built_links")
+        return Scene(nodes, v0, v1, v2, cc, src, {"build_ms": ms.value}, links), ms.value
 
     def get_normals(self) -> np.ndarray:
         out = np.empty((self.num_tris, 4), dtype=np.float32)

@@ -73,6 +73,7 @@ struct rt_context {
     float* d_ref_nodes = nullptr;
     float4 *d_ref_v0 = nullptr, *d_ref_v1 = nullptr, *d_ref_v2 = nullptr, *d_ref_col = nullptr;
     uint32_t* d_ref_src = nullptr;
+    int32_t* d_ref_links = nullptr;
     int built_nodes = 0;
     float last_build_ms = 0.0f;
     // builder workspace, kept between builds (a per-frame rebuild must not pay for fresh allocations)
@@ -140,6 +141,7 @@ static void free_ref(rt_context* c) {
     dfree(c->d_ref_v2);
     dfree(c->d_ref_col);
     dfree(c->d_ref_src);
+    dfree(c->d_ref_links);
     c->bd.ref_cap = 0;
     c->bd.ref_valid = false;
 }
@@ -475,6 +477,8 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
         return fail(c, RT_EINVAL, "scene pointers must not be NULL");
     const int N = s->num_nodes, T = s->num_tris;
     if (N < 1 || T < 1) return fail(c, RT_EINVAL, "scene needs at least one node and one triangle");
+    if (!s->links && (N > (1 << 24) || T > (1 << 24)))
+        return fail(c, RT_ELIMIT, "float-encoded ids cannot address %d nodes / %d triangles: pass rt_scene.links", N, T);
 
     // Pass 1: validate the tree depth-first (first child first) and remember the visiting order.
     struct Visit {
@@ -505,8 +509,8 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
             v.parent = it.parent;
             v.slot = it.slot;
             v.leaf = std::fabs(nd[8] - 1.0f) <= RT_EPS;  // raytrace.glsl:155
-            v.a = (int)nd[9];                             // raytrace.glsl:157-158,167-168
-            v.b = (int)nd[10];
+            v.a = s->links ? s->links[2 * (size_t)it.node] : (int)nd[9];  // raytrace.glsl:157-158,167-168
+            v.b = s->links ? s->links[2 * (size_t)it.node + 1] : (int)nd[10];
             int pos = (int)order.size();
             if (v.leaf) {
                 if (v.b >= v.a && (v.a < 0 || v.b >= T))
@@ -879,6 +883,33 @@ int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
     return RT_OK;
 }
 
+// The reference-layout copy of a device-built scene is made on the first download after a build.
+static int ensure_ref_layout(rt_context* c) {
+    BuiltData& bd = c->bd;
+    if (bd.ref_valid) return RT_OK;
+    const int nf = bd.nf;
+    const size_t T = (size_t)nf;
+    if (bd.ref_cap < nf) {
+        free_ref(c);
+        HIPCHK(c, hipMalloc(&c->d_ref_nodes, (size_t)2 * T * 12 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_ref_v0, T * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_ref_v1, T * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_ref_v2, T * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_ref_col, T * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_ref_src, T * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->d_ref_links, (size_t)2 * T * 2 * sizeof(int32_t)));
+        bd.ref_cap = nf;
+    }
+    const dim3 blk(BB_BLOCK);
+    hipLaunchKernelGGL(k_build_emit_ref_nodes, dim3((c->built_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, c->stream, bd.s, c->built_nodes,
+                       c->d_ref_nodes, c->d_ref_links);
+    hipLaunchKernelGGL(k_build_emit_ref_tris, dim3((nf + BB_BLOCK - 1) / BB_BLOCK), blk, 0, c->stream, bd.s, bd.cur, nf, bd.d_verts,
+                       bd.d_faces, bd.d_fcol, c->d_ref_v0, c->d_ref_v1, c->d_ref_v2, c->d_ref_col, c->d_ref_src);
+    HIPCHK(c, hipGetLastError());
+    bd.ref_valid = true;
+    return RT_OK;
+}
+
 int rt_get_built_scene(rt_context* c, int32_t* num_nodes, int32_t* num_tris, float* nodes, float* triv0, float* triv1,
                        float* triv2, float* colours, int32_t* tri_src, float* build_ms) {
     if (!c) return RT_EINVAL;
@@ -888,34 +919,27 @@ int rt_get_built_scene(rt_context* c, int32_t* num_nodes, int32_t* num_tris, flo
     if (build_ms) *build_ms = c->last_build_ms;
     if (!nodes && !triv0 && !triv1 && !triv2 && !colours && !tri_src) return RT_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    BuiltData& bd = c->bd;
-    const int nf = bd.nf;
-    const size_t T = (size_t)nf;
-    if (!bd.ref_valid) {  // the reference-layout copy is made on the first download after a build
-        if (bd.ref_cap < nf) {
-            free_ref(c);
-            HIPCHK(c, hipMalloc(&c->d_ref_nodes, (size_t)2 * T * 12 * sizeof(float)));
-            HIPCHK(c, hipMalloc(&c->d_ref_v0, T * sizeof(float4)));
-            HIPCHK(c, hipMalloc(&c->d_ref_v1, T * sizeof(float4)));
-            HIPCHK(c, hipMalloc(&c->d_ref_v2, T * sizeof(float4)));
-            HIPCHK(c, hipMalloc(&c->d_ref_col, T * sizeof(float4)));
-            HIPCHK(c, hipMalloc(&c->d_ref_src, T * sizeof(uint32_t)));
-            bd.ref_cap = nf;
-        }
-        const dim3 blk(BB_BLOCK);
-        hipLaunchKernelGGL(k_build_emit_ref_nodes, dim3((c->built_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, c->stream, bd.s, c->built_nodes,
-                           c->d_ref_nodes);
-        hipLaunchKernelGGL(k_build_emit_ref_tris, dim3((nf + BB_BLOCK - 1) / BB_BLOCK), blk, 0, c->stream, bd.s, bd.cur, nf, bd.d_verts,
-                           bd.d_faces, bd.d_fcol, c->d_ref_v0, c->d_ref_v1, c->d_ref_v2, c->d_ref_col, c->d_ref_src);
-        HIPCHK(c, hipGetLastError());
-        bd.ref_valid = true;
-    }
+    int rc = ensure_ref_layout(c);
+    if (rc != RT_OK) return rc;
+    const size_t T = (size_t)c->bd.nf;
     if (nodes) HIPCHK(c, hipMemcpyAsync(nodes, c->d_ref_nodes, (size_t)c->built_nodes * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (triv0) HIPCHK(c, hipMemcpyAsync(triv0, c->d_ref_v0, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (triv1) HIPCHK(c, hipMemcpyAsync(triv1, c->d_ref_v1, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (triv2) HIPCHK(c, hipMemcpyAsync(triv2, c->d_ref_v2, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (colours) HIPCHK(c, hipMemcpyAsync(colours, c->d_ref_col, T * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (tri_src) HIPCHK(c, hipMemcpyAsync(tri_src, c->d_ref_src, T * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_get_built_links(rt_context* c, int32_t* links) {
+    if (!c) return RT_EINVAL;
+    if (!links) return fail(c, RT_EINVAL, "links is NULL");
+    if (!c->has_scene || !c->built_nodes) return fail(c, RT_ENOSCENE, "the current scene was not built on the device");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_ref_layout(c);
+    if (rc != RT_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(links, c->d_ref_links, (size_t)c->built_nodes * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

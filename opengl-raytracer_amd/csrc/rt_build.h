@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int 
 }
 
 // the same tree in the reference's buffer layout (scene-loader.h:7-15), produced on demand for downloads
-__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_ref_nodes(BuildState s, int num_nodes, float* ref_nodes) {
+__global__ __launch_bounds__(BB_BLOCK) void k_build_emit_ref_nodes(BuildState s, int num_nodes, float* ref_nodes, int32_t* links) {
     int i = blockIdx.x * BB_BLOCK + threadIdx.x;
     if (i >= num_nodes) return;
     float4 lo = s.nmin[i], hi = s.nmax[i];
@@ -1233,6 +1233,9 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_ref_nodes(BuildState s,
     r[9] = c0 < 0 ? (float)s.nstart[i] : (float)c0;
     r[10] = c0 < 0 ? (float)(s.nstart[i] + s.ncount[i] - 1) : (float)(c0 + 1);
     r[11] = 0.0f;
+    // the same pair as exact integers (floats stop being exact at 2^24)
+    links[2 * (size_t)i] = c0 < 0 ? s.nstart[i] : c0;
+    links[2 * (size_t)i + 1] = c0 < 0 ? s.nstart[i] + s.ncount[i] - 1 : c0 + 1;
 }
 
 __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_ref_tris(BuildState s, int cur, int n, const float* verts,

@@ -70,6 +70,7 @@ struct Scene {
     const float* triv2;
     const float* colours;
     const float* normals;  // numTris x 4 (std430 vec3[] stride)
+    const int32_t* links;  // optional exact (a, b) per node (rt_scene.links); NULL: the reference's float-encoded ids
 };
 
 inline rt_vec3 load3(const float* base, int i) { return rt_v3(base[4 * i], base[4 * i + 1], base[4 * i + 2]); }
@@ -139,8 +140,8 @@ HitInfo closest_hit(const Scene& sc, const Ray& ray, PixelCounters& pc) {
         const float* node = sc.bvh + 12 * bvhIndex;
         bool isLeaf = rt_abs(node[8] - 1.0f) <= RT_EPS;
         if (isLeaf) {
-            int triangleStart = (int)node[9];
-            int triangleEnd = (int)node[10];
+            int triangleStart = sc.links ? sc.links[2 * (size_t)bvhIndex] : (int)node[9];
+            int triangleEnd = sc.links ? sc.links[2 * (size_t)bvhIndex + 1] : (int)node[10];
             for (int k = triangleStart; k <= triangleEnd; k++) {
                 float triangleDist = tri_distance(sc, ray, k, pc);
                 if (triangleDist < info.dist) {
@@ -149,8 +150,8 @@ HitInfo closest_hit(const Scene& sc, const Ray& ray, PixelCounters& pc) {
                 }
             }
         } else {
-            int child1 = (int)node[9];
-            int child2 = (int)node[10];
+            int child1 = sc.links ? sc.links[2 * (size_t)bvhIndex] : (int)node[9];
+            int child2 = sc.links ? sc.links[2 * (size_t)bvhIndex + 1] : (int)node[10];
             float d1 = box_distance(ray, node_min(sc, child1), node_max(sc, child1), pc);
             float d2 = box_distance(ray, node_min(sc, child2), node_max(sc, child2), pc);
             if (d1 < d2) {
@@ -322,6 +323,7 @@ Scene make_scene(const rt_scene* s, const float* normals) {
     sc.triv2 = s->triv2;
     sc.colours = s->colours;
     sc.normals = normals;
+    sc.links = s->links;
     return sc;
 }
 

@@ -423,3 +423,22 @@ def test_large_image_uses_smaller_batches(pkg, gpu_ctx, scenes):
     b.free()
     assert np.array_equal(bits(img_a), bits(img_b))
     assert img_a[..., 3].min() == 2.0 and img_a[..., :3].max() <= 1.0 and img_a[..., :3].min() >= 0.0
+
+
+def test_upload_with_integer_links(pkg, oracle, scenes):
+    """rt_upload_scene reads the node ids from rt_scene.links when given (float ids poisoned)."""
+    scene = scenes("teapot")
+    nodes = scene.nodes.copy()
+    links = nodes[:, 9:11].astype(np.int32)
+    nodes[:, 9:11] = -12345.0
+    linked = pkg.Scene(nodes, scene.triv0, scene.triv1, scene.triv2, scene.colours, links=links)
+    cam = pkg.make_camera()
+    ctx = pkg.RenderContext(0)
+    ctx.upload_scene(linked)
+    p = pkg.make_params(160, 90, frames=2)
+    want, _ = oracle.render(scene, cam, p)
+    assert np.array_equal(bits(ctx.render(cam, p)), bits(want))
+    # poisoned ids without links: not a tree, refused on the host
+    with pytest.raises(RuntimeError):
+        ctx.upload_scene(pkg.Scene(nodes, scene.triv0, scene.triv1, scene.triv2, scene.colours))
+    ctx.close()
