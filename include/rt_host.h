@@ -52,6 +52,8 @@ typedef struct rt_host_scene {
     float* triv1;
     float* triv2;
     int32_t* tri_src;
+    int32_t* links;         /* num_nodes x 2: the (a, b) of every node as exact integers, taken from the builder's tree and
+                               not from the float serialisation (bvh.cpp:177-187), which is exact only up to 2^24 */
 } rt_host_scene;
 
 /* OBJ reader with the reference's grammar (obj-reader.cpp:22-38): lines "v x y z",

@@ -52,6 +52,7 @@ class HostScene(C.Structure):
         ("triv1", c_float_p),
         ("triv2", c_float_p),
         ("tri_src", c_int32_p),
+        ("links", c_int32_p),
     ]
 
 
@@ -298,6 +299,7 @@ def _scene_from_host(hs: HostScene, colour_seed: int) -> Scene:
     v1 = np.ctypeslib.as_array(hs.triv1, shape=(t, 4)).copy()
     v2 = np.ctypeslib.as_array(hs.triv2, shape=(t, 4)).copy()
     src = np.ctypeslib.as_array(hs.tri_src, shape=(t,)).copy()
+    links = np.ctypeslib.as_array(hs.links, shape=(n, 2)).copy()
     stats = {
         "num_leaves": hs.num_leaves,
         "min_leaf_size": hs.min_leaf_size,
@@ -305,7 +307,7 @@ def _scene_from_host(hs: HostScene, colour_seed: int) -> Scene:
         "max_depth": hs.max_depth,
         "num_vertices": hs.num_vertices,
     }
-    return Scene(nodes, v0, v1, v2, make_colours(colour_seed, t), src, stats)
+    return Scene(nodes, v0, v1, v2, make_colours(colour_seed, t), src, stats, links)
 
 
 def load_scene(obj_path: str, colour_seed: int = 1) -> Scene:

@@ -287,6 +287,7 @@ int rt_host_build_scene(const float* vertices, int32_t num_vertices, const uint3
     out->triv1 = alloc_n<float>((size_t)num_faces * 4);
     out->triv2 = alloc_n<float>((size_t)num_faces * 4);
     out->tri_src = alloc_n<int32_t>((size_t)num_faces);
+    out->links = alloc_n<int32_t>(nodes.size() * 2);
     for (size_t i = 0; i < nodes.size(); ++i) {
         const NodeOut& n = nodes[i];
         float* o = out->nodes + 12 * i;
@@ -296,6 +297,8 @@ int rt_host_build_scene(const float* vertices, int32_t num_vertices, const uint3
         o[9] = (float)n.a;
         o[10] = (float)n.b;
         o[11] = 0.0f;
+        out->links[2 * i] = (int32_t)n.a;
+        out->links[2 * i + 1] = (int32_t)n.b;
     }
     for (int i = 0; i < num_faces; ++i) {
         // indices come back out of the float row by truncation (bvh.cpp:162-164)
@@ -331,6 +334,7 @@ void rt_host_free_scene(rt_host_scene* s) {
     std::free(s->triv1);
     std::free(s->triv2);
     std::free(s->tri_src);
+    std::free(s->links);
     std::memset(s, 0, sizeof(*s));
 }
 

@@ -49,6 +49,7 @@ Raytracer* raytraceInit(SceneData* sceneData, int screenWidth, int screenHeight,
     s.triv1 = &sceneData->triv1[0][0];
     s.triv2 = &sceneData->triv2[0][0];
     s.colours = &sceneData->triangleColours[0][0];
+    s.links = sceneData->nodeLinks.empty() ? nullptr : sceneData->nodeLinks.data();
     check(rt, rt_upload_scene(rt->ctx, &s), "rt_upload_scene");
     return rt;
 }

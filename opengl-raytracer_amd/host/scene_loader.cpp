@@ -18,6 +18,7 @@ SceneData* loadScene(const std::string& objPath, unsigned colourSeed) {
     std::memcpy(s->triv0.data(), hs.triv0, sizeof(float) * 4 * (size_t)hs.num_tris);
     std::memcpy(s->triv1.data(), hs.triv1, sizeof(float) * 4 * (size_t)hs.num_tris);
     std::memcpy(s->triv2.data(), hs.triv2, sizeof(float) * 4 * (size_t)hs.num_tris);
+    s->nodeLinks.assign(hs.links, hs.links + 2 * (size_t)hs.num_nodes);
     s->triangleColours.resize((size_t)hs.num_tris);
     rt_host_make_colours(colourSeed, hs.num_tris, &s->triangleColours[0][0]);
     rt_host_free_scene(&hs);

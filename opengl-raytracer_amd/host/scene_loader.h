@@ -3,6 +3,7 @@
 // the reference generates inside initBuffers (raytrace.cpp:44-52) made explicit.
 #pragma once
 #include <array>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -15,6 +16,7 @@ struct SceneData {
     std::vector<AlignedMat3> alignedBVHNodes;
     std::vector<std::array<float, 4>> triv0, triv1, triv2;
     std::vector<std::array<float, 4>> triangleColours;  // rgb + 1
+    std::vector<int32_t> nodeLinks;  // not in the reference: (a, b) of every node as exact integers (rt_scene.links)
 };
 
 // loadScene() for an explicit path (the reference compiles "../models/teapot.obj" in, constants.h:14).

@@ -198,3 +198,12 @@ def test_compare_tool(tmp_path):
     ids2 = np.array([[0, 5], [7, -1]]); t2 = np.array([[1.0, 2.0001], [3.5, np.inf]], dtype=np.float32)
     r = m.compare_ids(ids, t, ids2, t2)
     assert r["mismatch"] == 2 and r["epsilon_ties"] == 1 and r["real"] == 1
+
+
+def test_host_scene_carries_exact_integer_links(pkg, scenes):
+    """rt_host_scene.links: the (a, b) of every node as integers, straight from the builder's tree; below 2^24 they
+    equal the reference's float-encoded ids."""
+    for name in ("model", "teapot"):
+        s = scenes(name)
+        assert s.links is not None and s.links.shape == (s.num_nodes, 2)
+        assert np.array_equal(s.links, s.nodes[:, 9:11].astype(np.int32))
