@@ -207,3 +207,14 @@ def test_host_scene_carries_exact_integer_links(pkg, scenes):
         s = scenes(name)
         assert s.links is not None and s.links.shape == (s.num_nodes, 2)
         assert np.array_equal(s.links, s.nodes[:, 9:11].astype(np.int32))
+
+
+def test_host_code_is_clean_under_sanitizers():
+    """Host ingest + oracle compiled with ASan/UBSan into oracle/_ref/san_check and run over the fixtures."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    exe = os.path.join(ROOT, "oracle", "_ref", "san_check")
+    for name in ("model", "teapot"):
+        r = subprocess.run([exe, os.path.join(FIXTURES, name + ".obj")], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="2"))
+        assert r.returncode == 0 and "san_check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
