@@ -1,6 +1,6 @@
 // Persistent path kernel: the default pipeline of the render path on MI355X.
 //
-// One launch renders a BATCH of frames.  The grid is two 768-thread workgroups per CU (24 waves, 6 per SIMD); every
+// One launch renders a BATCH of frames.  The grid is two 1024-thread workgroups per CU (32 waves, 8 per SIMD); every
 // wave is an independent worker that keeps its 64 lanes busy with paths drawn from a pool of (frame, 8x8 pixel tile)
 // items, so that lanes whose path has ended (60 % of primary rays leave the scene at once) do not idle while
 // their neighbours traverse.  Each wave alternates two phases, each of which runs one kind of code on as many
@@ -17,10 +17,10 @@
 // instructions per step and how many lanes each of them serves.
 //
 // Memory placement (LDS is 160 KiB per CU, 80 KiB per workgroup):
-//   traversal stacks   8 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict: 48 KiB;
+//   traversal stacks   8 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict: 64 KiB;
 //                      deeper entries (rare) spill to HBM, coalesced across the wave
-//   top of the BVH     the first PT_CACHE inner-node records (breadth-first, ~9 levels) are staged in LDS once
-//                      per workgroup: 32 KiB.  Quads of a record are XOR-swizzled so that lanes reading different
+//   top of the BVH     the first PT_CACHE inner-node records (breadth-first, ~8 levels) are staged in LDS once
+//                      per workgroup: 16 KiB.  Quads of a record are XOR-swizzled so that lanes reading different
 //                      records spread over all 16-byte bank slots
 //   everything else    registers: ray, throughput, RNG state, pixel, bounce index, traversal cursor
 //
@@ -34,10 +34,10 @@
 #include "rt_device.h"
 
 #ifndef PT_BLOCK
-#define PT_BLOCK 768           // threads per workgroup (12 waves)
-#define PT_BLOCKS_PER_CU 2     // -> 24 waves per CU, 6 per SIMD (needs <= 80 VGPRs)
+#define PT_BLOCK 1024          // threads per workgroup (16 waves)
+#define PT_BLOCKS_PER_CU 2     // -> 32 waves per CU, 8 per SIMD, the hardware maximum (needs <= 64 VGPRs)
 #define PT_STACK 8             // traversal-stack entries per lane kept in LDS
-#define PT_CACHE 511           // inner-node records staged in LDS (64 B each); 2 x (stacks+cache+counter) <= 160 KiB
+#define PT_CACHE 254           // inner-node records staged in LDS (64 B each); 2 x (stacks+cache+counter) <= 160 KiB
 #endif
 #define PT_MIN_TRAV 40         // leave the traversal phase when fewer lanes than this still traverse ...
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
