@@ -34,7 +34,7 @@
 #define RT_REF_IDLE ((int)0x80000000)    // "no node": what an idle lane of the persistent kernel holds
 #define RT_REF_EMPTY ((int)0x80000001)   // leaf with an empty triangle range
 #define RT_BLOCK 256          // threads per workgroup of every kernel here (4 waves)
-#define RT_LDS_STACK 16       // traversal-stack entries per lane kept in LDS; deeper ones spill to HBM
+#define RT_LDS_STACK 8        // traversal-stack entries per lane kept in LDS; deeper ones spill to HBM
 
 struct DScene {
     const float4* nodes;
