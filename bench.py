@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-VALU_PEAK_LANE_OPS = 256 * 64 * 2.4e9  # 256 CUs x 64 lanes/clk x 2.4 GHz = 39.3 T fp32 lane-ops/s (an FMA counts once, unpacked)
+VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T fp32 lane-ops/s (157.3 TFLOP/s with FMAs; an FMA counts once here)
 WORKLOADS = {
     # name: (obj, camera position, width, height)
     "dragon80k_1080p": ("dragon80k.obj", (0.0, 0.0, -5.5), 1920, 1080),

@@ -13,8 +13,9 @@
 //   traverse  ordered BVH traversal; every iteration runs ONE kind of step (inner-node visit or triangle test),
 //             chosen by a weighted vote of the lanes, until too few lanes are still traversing.
 //
-// The kernel is bound by VALU issue (98 % of all issue slots on dragon80k), so what matters is the number of vector
-// instructions per step and how many lanes each of them serves.
+// The kernel is bound by VALU issue and the latency between dependent steps (on dragon80k it uses ~70 % of the issue
+// rate the SIMDs sustain; a wave instruction costs the same whatever its EXEC mask), so what matters is the number of
+// vector instructions per step, how many lanes each of them serves and how many waves are resident to cover latency.
 //
 // Memory placement (LDS is 160 KiB per CU, 80 KiB per workgroup):
 //   traversal stacks   8 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict: 64 KiB;
