@@ -93,8 +93,8 @@ struct rt_context {
     // persistent path kernel
     int num_cus = 0;
     int cache_recs = 0;           // inner-node records that are laid out breadth-first at the front
-    float4* d_samples = nullptr;  // [PT_MAX_BATCH][pixels] staging
-    size_t samples_pixels = 0;
+    float4* d_samples = nullptr;  // [frames of one launch][pixels] staging
+    size_t samples_bytes = 0;
     uint2* d_pspill = nullptr;
     size_t pspill_entries = 0;
 
@@ -134,6 +134,19 @@ static void dfree(T*& p) {
     p = nullptr;
 }
 
+// A device allocation that lives for one call.
+template <class T>
+struct DevTmp {
+    T* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, count * sizeof(T)); }
+};
+
 static void free_ref(rt_context* c) {
     dfree(c->d_ref_nodes);
     dfree(c->d_ref_v0);
@@ -168,7 +181,7 @@ static void free_buffers(rt_context* c) {
     c->cap_slots = 0;
     c->spill_entries = 0;
     dfree(c->d_samples);
-    c->samples_pixels = 0;
+    c->samples_bytes = 0;
     dfree(c->d_pspill);
     c->pspill_entries = 0;
 }
@@ -267,13 +280,15 @@ static uint32_t paths_batch(size_t pixels) {
 
 static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
-    if (pixels <= c->samples_pixels && want_spill <= c->pspill_entries) return RT_OK;
+    // sized in bytes: a smaller image may render more frames per launch than the one the buffer was made for
+    const size_t want_bytes = (size_t)paths_batch(pixels) * pixels * sizeof(float4);
+    if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries) return RT_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (pixels > c->samples_pixels) {
+    if (want_bytes > c->samples_bytes) {
         dfree(c->d_samples);
-        c->samples_pixels = 0;
-        HIPCHK(c, hipMalloc(&c->d_samples, (size_t)paths_batch(pixels) * pixels * sizeof(float4)));
-        c->samples_pixels = pixels;
+        c->samples_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_samples, want_bytes));
+        c->samples_bytes = want_bytes;
     }
     if (want_spill > c->pspill_entries) {
         dfree(c->d_pspill);
@@ -576,7 +591,8 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
                                      0.0f, 0.0f, 0.0f, 0.0f};
                     tris.insert(tris.end(), rec, rec + 16);
                 }
-                if (tris.size() / 16 > (size_t)0x7ffffff0) return fail(c, RT_ELIMIT, "too many triangle records");
+                // leaves of a malformed scene may overlap; the records they expand to obey the same limit
+                if (tris.size() / 16 >= ((size_t)1 << 26)) return fail(c, RT_ELIMIT, "leaves expand to more than 2^26 - 1 triangle records");
             }
         } else {
             ref = rec_of[i];
@@ -604,24 +620,27 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     if (nrec) HIPCHK(c, hipMemcpyAsync(c->d_nodes, recs.data(), nrec * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (ntri) HIPCHK(c, hipMemcpyAsync(c->d_tris, tris.data(), ntri * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     // the normals kernel reads the caller's vertex arrays as the reference's does (normals.glsl:15-17)
-    float4 *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *col = nullptr;
-    size_t vb = (size_t)T * sizeof(float4);
-    HIPCHK(c, hipMalloc(&v0, vb));
-    HIPCHK(c, hipMalloc(&v1, vb));
-    HIPCHK(c, hipMalloc(&v2, vb));
-    HIPCHK(c, hipMalloc(&col, vb));
-    HIPCHK(c, hipMemcpyAsync(v0, s->triv0, vb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(v1, s->triv1, vb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(v2, s->triv2, vb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(col, s->colours, vb, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_normals, dim3((T + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, v0, v1, v2, col,
-                       c->d_shade, T);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    dfree(v0);
-    dfree(v1);
-    dfree(v2);
-    dfree(col);
+    {
+        DevTmp<float4> v0, v1, v2, col;
+        const size_t vb = (size_t)T * sizeof(float4);
+        HIPCHK(c, v0.alloc((size_t)T));
+        HIPCHK(c, v1.alloc((size_t)T));
+        HIPCHK(c, v2.alloc((size_t)T));
+        HIPCHK(c, col.alloc((size_t)T));
+        HIPCHK(c, hipMemcpyAsync(v0.p, s->triv0, vb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(v1.p, s->triv1, vb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(v2.p, s->triv2, vb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(col.p, s->colours, vb, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_normals, dim3((T + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, v0.p, v1.p, v2.p, col.p,
+                           c->d_shade, T);
+        hipError_t e = hipGetLastError();
+        // the temporaries are released only after the stream has drained, also on failure
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            free_scene(c);
+            return fail(c, RT_EDEVICE, "scene upload: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+    }
 
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
@@ -1108,10 +1127,12 @@ int rt_primary_hits(rt_context* c, const rt_camera* cam, int32_t width, int32_t 
     int rc = ensure_buffers(c, width, height);
     if (rc != RT_OK) return rc;
     size_t pixels = (size_t)width * height;
-    int* d_ids = nullptr;
-    float* d_t = nullptr;
-    HIPCHK(c, hipMalloc(&d_ids, pixels * sizeof(int)));
-    HIPCHK(c, hipMalloc(&d_t, pixels * sizeof(float)));
+    DevTmp<int> ids;
+    DevTmp<float> ts;
+    HIPCHK(c, ids.alloc(pixels));
+    HIPCHK(c, ts.alloc(pixels));
+    int* const d_ids = ids.p;
+    float* const d_t = ts.p;
     DCamera dc = make_dcamera(cam, width, height);
     int tiles_x = (width + 15) / 16, tiles = tiles_x * ((height + 15) / 16);
     hipLaunchKernelGGL(k_primary_hits, dim3(tiles), dim3(RT_BLOCK), 0, c->stream, c->sc, dc, tiles_x, d_ids, d_t,
@@ -1119,9 +1140,8 @@ int rt_primary_hits(rt_context* c, const rt_camera* cam, int32_t width, int32_t 
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_ids, d_ids, pixels * sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_t, pixels * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dfree(d_ids);
-    dfree(d_t);
+    const hipError_t es = hipStreamSynchronize(c->stream);  // always drain before the temporaries go
+    if (e == hipSuccess) e = es;
     if (e != hipSuccess) return fail(c, RT_EDEVICE, "rt_primary_hits: %s", hipGetErrorString(e));
     return RT_OK;
 }
@@ -1183,18 +1203,18 @@ int rt_selftest_math(rt_context* c, const float* x, int32_t n, float* out) {
     if (!c) return RT_EINVAL;
     if (!x || !out || n <= 0) return fail(c, RT_EINVAL, "bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    float *dx = nullptr, *dout = nullptr;
-    HIPCHK(c, hipMalloc(&dx, (size_t)n * sizeof(float)));
-    HIPCHK(c, hipMalloc(&dout, (size_t)n * 6 * sizeof(float)));
+    DevTmp<float> tx, tout;
+    HIPCHK(c, tx.alloc((size_t)n));
+    HIPCHK(c, tout.alloc((size_t)n * 6));
+    float *const dx = tx.p, *const dout = tout.p;
     hipError_t e = hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, dx, n, dout);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    dfree(dx);
-    dfree(dout);
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = es;
     if (e != hipSuccess) return fail(c, RT_EDEVICE, "rt_selftest_math: %s", hipGetErrorString(e));
     return RT_OK;
 }

@@ -407,9 +407,15 @@ def test_band_argument_errors(pkg, gpu_ctx, scenes):
 
 def test_large_image_uses_smaller_batches(pkg, gpu_ctx, scenes):
     """At 8192x4096 the staged samples of 8 frames would take 4.3 GB; the library renders fewer frames per launch
-    (2 GiB of staging at most).  Rendering 5 frames in one call must equal five single-frame dispatches bit for bit."""
+    (2 GiB of staging at most).  Rendering 5 frames in one call must equal five single-frame dispatches bit for bit.
+    A taller image is rendered first: it stages 3 frames of 655 MB, less than the 4 x 537 MB the second image needs, so
+    the staging area has to grow although the pixel count shrinks."""
     gpu_ctx.upload_scene(scenes("teapot"))
     cam = pkg.make_camera()
+    tall = pkg.DeviceBuffer(8192 * 5000 * 16)
+    gpu_ctx.render_device(cam, pkg.make_params(8192, 5000, frames=3), tall.ptr)
+    gpu_ctx.synchronize()
+    tall.free()
     W, H = 8192, 4096
     nbytes = W * H * 16
     a, b = pkg.DeviceBuffer(nbytes), pkg.DeviceBuffer(nbytes)
