@@ -105,6 +105,28 @@ __device__ __forceinline__ float tri_dist(rt_vec3 o, rt_vec3 d, rt_vec3 a, rt_ve
     return t > RT_EPS ? t : RT_INF;
 }
 
+// The same function without early exits: every lane computes u, v and t and the rejections are folded into one select.
+// Identical results (the rejected lanes' values are never used, the tests are the same expressions); for a wave whose
+// lanes leave at different points this is cheaper than one masked branch per exit, and all three loads of the triangle
+// record are issued together.
+__device__ __forceinline__ float tri_dist_flat(rt_vec3 o, rt_vec3 d, rt_vec3 a, rt_vec3 e1, rt_vec3 e2) {
+    rt_vec3 p = rt_cross(d, e2);
+    float det = rt_dot(e1, p);
+    float inv_det = 1.0f / det;
+    rt_vec3 s = rt_sub(o, a);
+    float u = inv_det * rt_dot(s, p);
+    rt_vec3 q = rt_cross(s, e1);
+    float v = inv_det * rt_dot(d, q);
+    float t = inv_det * rt_dot(e2, q);
+    int rej = (int)(rt_abs(det) < RT_EPS);
+    rej |= (int)(u < 0.0f) & (int)(rt_abs(u) > RT_EPS);
+    rej |= (int)(u > 1.0f) & (int)(rt_abs(u - 1.0f) > RT_EPS);
+    rej |= (int)(v < 0.0f) & (int)(rt_abs(v) > RT_EPS);
+    rej |= (int)(u + v > 1.0f) & (int)(rt_abs((u + v) - 1.0f) > RT_EPS);
+    rej |= (int)!(t > RT_EPS);
+    return rej ? RT_INF : t;
+}
+
 // Ordered depth-first closest hit.  Visit order, the `dist >= best` cull at pop, the strict `<`
 // updates and the tie rule (d1 == d2 visits child 2 first) are the reference's; the nearer child is
 // continued with directly instead of being pushed and popped again, which is the same sequence.

@@ -21,8 +21,8 @@
 //   traversal stacks   8 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict: 64 KiB;
 //                      deeper entries (rare) spill to HBM, coalesced across the wave
 //   top of the BVH     the first PT_CACHE inner-node records (breadth-first, ~8 levels) are staged in LDS once
-//                      per workgroup: 16 KiB.  Quads of a record are XOR-swizzled so that lanes reading different
-//                      records spread over all 16-byte bank slots
+//                      per workgroup: 16 KiB, stored quad by quad (all first 16-byte quads, then all second ones, ...)
+//                      so that lanes reading different records spread over all 16-byte bank slots
 //   everything else    registers: ray, throughput, RNG state, pixel, bounce index, traversal cursor
 //
 // A finished path stores (throughput.rgb, dir.y) into a staging array [frame][pixel]; k_accumulate evaluates the
@@ -99,9 +99,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     __shared__ uint32_t s_next;
     const int tid = threadIdx.x;
 
+    // quad q of record r sits at s_nodes[q * PT_CACHE + r]: a lane's four reads differ by constant offsets, and lanes
+    // that read the same quad of different records spread over all eight 16-byte bank slots
     for (int i = tid; i < a.cache_recs * 4; i += PT_BLOCK) {
         int r = i >> 2, q = i & 3;
-        s_nodes[(r << 2) + (q ^ ((r >> 2) & 3))] = sc.nodes[i];
+        s_nodes[q * PT_CACHE + r] = sc.nodes[i];
     }
     if (tid == 0) s_next = 0;
     __syncthreads();
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
 #define PT_PUT(i_, ref_, dist_)                                              \
     do {                                                                     \
         uint2 v_ = make_uint2((uint32_t)(ref_), rt_f2u(dist_));             \
-        if ((i_) < PT_STACK)                                                 \
+        if ((i_) < PT_STACK)                                    \
             *PT_SLOT(i_) = u32x2{v_.x, v_.y};                                \
         else                                                                 \
             spill_store(spill + (size_t)((i_)-PT_STACK) * spill_stride, v_); \
@@ -269,11 +271,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             const bool want_leaf = (uint32_t)cur > 0x80000000u;
             const unsigned long long mi = __builtin_amdgcn_ballot_w64(want_inner), ml = __builtin_amdgcn_ballot_w64(want_leaf);
             const uint32_t ni = (uint32_t)__builtin_popcountll(mi), nl = (uint32_t)__builtin_popcountll(ml);
-            if (ni + nl == 0) break;
             if (ni + nl < (uint32_t)a.min_trav) {
+                if (ni + nl == 0) break;
                 // is there anything the service phase could do for the lanes that do not traverse?
-                const bool serviceable = exhausted ? __builtin_amdgcn_ballot_w64(state == ST_DONE) != 0ull : true;
-                if (serviceable) break;
+                if (!exhausted || __builtin_amdgcn_ballot_w64(state == ST_DONE) != 0ull) break;
             }
             if (ni * (uint32_t)a.w_inner >= nl * (uint32_t)a.w_leaf) {
                 if (want_leaf) { DIAG(3, 1); }
@@ -290,26 +291,25 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     {
                         const unsigned long long staged = __builtin_amdgcn_ballot_w64(cur < a.cache_recs);
                         const uint32_t cc = (uint32_t)cur;
-                        const uint32_t base = nodes_lds + (cc << 6), x = (cc >> 2) & 3u;
+                        const uint32_t base = nodes_lds + (cc << 4);
                         const uint32_t rec_off = cc << 6;  // byte offset from sc.nodes (the upload limits records to 4 GiB)
                         unsigned long long keep;
                         asm volatile(
                             "s_mov_b64 %4, exec\n\t"
                             "s_and_b64 exec, %4, %5\n\t"
                             "ds_read_b128 %0, %6\n\t"
-                            "ds_read_b128 %1, %7\n\t"
-                            "ds_read_b128 %2, %8\n\t"
-                            "ds_read_b128 %3, %9\n\t"
+                            "ds_read_b128 %1, %6 offset:%9\n\t"
+                            "ds_read_b128 %2, %6 offset:%10\n\t"
+                            "ds_read_b128 %3, %6 offset:%11\n\t"
                             "s_andn2_b64 exec, %4, %5\n\t"
-                            "global_load_dwordx4 %0, %10, %11\n\t"
-                            "global_load_dwordx4 %1, %10, %11 offset:16\n\t"
-                            "global_load_dwordx4 %2, %10, %11 offset:32\n\t"
-                            "global_load_dwordx4 %3, %10, %11 offset:48\n\t"
+                            "global_load_dwordx4 %0, %7, %8\n\t"
+                            "global_load_dwordx4 %1, %7, %8 offset:16\n\t"
+                            "global_load_dwordx4 %2, %7, %8 offset:32\n\t"
+                            "global_load_dwordx4 %3, %7, %8 offset:48\n\t"
                             "s_mov_b64 exec, %4\n\t"
                             "s_waitcnt vmcnt(0) lgkmcnt(0)"
                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&s"(keep)
-                            : "s"(staged), "v"(base + (x << 4)), "v"(base + ((1u ^ x) << 4)), "v"(base + ((2u ^ x) << 4)),
-                              "v"(base + ((3u ^ x) << 4)), "v"(rec_off), "s"(sc.nodes)
+                            : "s"(staged), "v"(base), "v"(rec_off), "s"(sc.nodes), "n"(PT_CACHE * 16), "n"(PT_CACHE * 32), "n"(PT_CACHE * 48)
                             : "memory");
                     }
                     if (COUNT) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         const float4* tr = (const float4*)((const char*)sc.tris + ((uint32_t)k << 6));  // 32-bit offset
                         float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
                         if (COUNT) cn.tri++;
-                        float t = tri_dist(p.o, p.d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
+                        float t = tri_dist_flat(p.o, p.d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
                         if (t < best) {
                             best = t;
                             best_id = (int)rt_f2u(t1.w);
