@@ -42,8 +42,8 @@
 #endif
 #define PT_MIN_TRAV 40         // leave the traversal phase when fewer lanes than this still traverse ...
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
-#define PT_W_INNER 2           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
-#define PT_W_LEAF 3            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
+#define PT_W_INNER 4           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
+#define PT_W_LEAF 7            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
 #define PT_MAX_BATCH 8         // frames per launch
 #define PT_STRIPE_TILES 2      // interleaved bands: a stripe is 2 tile rows = 16 pixel rows
 
@@ -252,7 +252,6 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
 #define PT_POP()                                             \
     for (;;) {                                               \
         if (sp == 0) {                                       \
-            state = ST_DONE;                                 \
             cur = RT_REF_IDLE;                               \
             break;                                           \
         }                                                    \
@@ -274,11 +273,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             if (ni + nl < (uint32_t)a.min_trav) {
                 if (ni + nl == 0) break;
                 // is there anything the service phase could do for the lanes that do not traverse?
-                if (!exhausted || __builtin_amdgcn_ballot_w64(state == ST_DONE) != 0ull) break;
+                if (!exhausted || __builtin_amdgcn_ballot_w64(state == ST_DONE || (state == ST_TRAV && cur == RT_REF_IDLE)) != 0ull) break;
             }
             if (ni * (uint32_t)a.w_inner >= nl * (uint32_t)a.w_leaf) {
                 if (want_leaf) { DIAG(3, 1); }
-                if (state == ST_DONE) { DIAG(9, 1); }
+                if (state == ST_DONE || (state == ST_TRAV && cur == RT_REF_IDLE)) { DIAG(9, 1); }
                 if (state == ST_NEED) { DIAG(11, 1); }
                 if (want_inner) {
                     DIAG(0, 1);
@@ -358,6 +357,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             }
         }
 #undef PT_POP
+        // a lane whose traversal ran out of nodes has its closest hit (or none): the loop only marks it idle
+        if (state == ST_TRAV && cur == RT_REF_IDLE) state = ST_DONE;
     }
     if (COUNT && a.counters) flush_counters6(cn, paths, a.counters);
 #ifdef PT_DIAG
