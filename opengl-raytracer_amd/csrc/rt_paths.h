@@ -92,6 +92,89 @@ __device__ __forceinline__ uint2 spill_load(const uint2* p) {
     return v;
 }
 
+
+// The tail of a traversal step, hand-scheduled for the common case that no lane touches the stack spill area.
+// v62/v63 are named explicitly because the 8-byte stack entry must sit in a register pair whose halves the code also
+// uses one by one.
+//
+// pt_pop_lds: the lanes of `need` pop until an entry survives the `dist >= best` cull (raytrace.glsl:151) or their
+// stack is empty (cur = RT_REF_IDLE).  stack0 = LDS byte address of the lane's slot 0; slots are 8 KiB apart.
+__device__ __forceinline__ void pt_pop_lds(unsigned long long need, uint32_t stack0, float best, int& sp, int& cur) {
+    unsigned long long save, np;
+    uint32_t addr;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_and_b64 %[np], %[need], exec\n\t"
+        "s_cbranch_scc0 Lpop_done%=\n"
+        "Lpop_loop%=:\n\t"
+        "s_mov_b64 exec, %[np]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[sp]\n\t"
+        "v_cndmask_b32_e32 %[cur], %[idle], %[cur], vcc\n\t"
+        "s_and_b64 %[np], %[np], vcc\n\t"
+        "s_cbranch_scc0 Lpop_done%=\n\t"
+        "s_mov_b64 exec, %[np]\n\t"
+        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
+        "v_lshl_add_u32 %[addr], %[sp], 13, %[stack0]\n\t"
+        "ds_read_b64 v[62:63], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_nge_f32_e32 vcc, v63, %[best]\n\t"
+        "v_cndmask_b32_e32 %[cur], %[cur], v62, vcc\n\t"
+        "s_andn2_b64 %[np], %[np], vcc\n\t"
+        "s_cbranch_scc1 Lpop_loop%=\n"
+        "Lpop_done%=:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [save] "=&s"(save), [np] "=&s"(np), [addr] "=&v"(addr), [sp] "+v"(sp), [cur] "+v"(cur)
+        : [need] "s"(need), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE)
+        : "vcc", "scc", "v62", "v63", "memory");
+}
+
+// pt_inner_tail_lds: after the two box tests of an inner node (distances d1, d2, child references r1, r2): push the
+// farther child if it can still hold a closer hit, continue with the nearer one or pop (raytrace.glsl:167-191; equal
+// distances visit child 2 first).
+__device__ __forceinline__ void pt_inner_tail_lds(float d1, float d2, int r1, int r2, uint32_t stack0, float best, int& sp, int& cur) {
+    unsigned long long save, np;
+    uint32_t addr;
+    int rn;
+    float dn;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[d1], %[d2]\n\t"
+        "v_cndmask_b32_e32 v62, %[r1], %[r2], vcc\n\t"
+        "v_cndmask_b32_e32 v63, %[d1], %[d2], vcc\n\t"
+        "v_cndmask_b32_e32 %[rn], %[r2], %[r1], vcc\n\t"
+        "v_cndmask_b32_e32 %[dn], %[d2], %[d1], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, v63, %[best]\n\t"
+        "s_and_b64 exec, %[save], vcc\n\t"
+        "v_lshl_add_u32 %[addr], %[sp], 13, %[stack0]\n\t"
+        "ds_write_b64 %[addr], v[62:63]\n\t"
+        "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[dn], %[best]\n\t"
+        "v_cndmask_b32_e32 %[cur], %[cur], %[rn], vcc\n\t"
+        "s_andn2_b64 %[np], %[save], vcc\n\t"
+        "s_cbranch_scc0 Ltail_done%=\n"
+        "Ltail_loop%=:\n\t"
+        "s_mov_b64 exec, %[np]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[sp]\n\t"
+        "v_cndmask_b32_e32 %[cur], %[idle], %[cur], vcc\n\t"
+        "s_and_b64 %[np], %[np], vcc\n\t"
+        "s_cbranch_scc0 Ltail_done%=\n\t"
+        "s_mov_b64 exec, %[np]\n\t"
+        "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
+        "v_lshl_add_u32 %[addr], %[sp], 13, %[stack0]\n\t"
+        "ds_read_b64 v[62:63], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_nge_f32_e32 vcc, v63, %[best]\n\t"
+        "v_cndmask_b32_e32 %[cur], %[cur], v62, vcc\n\t"
+        "s_andn2_b64 %[np], %[np], vcc\n\t"
+        "s_cbranch_scc1 Ltail_loop%=\n"
+        "Ltail_done%=:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [save] "=&s"(save), [np] "=&s"(np), [addr] "=&v"(addr), [rn] "=&v"(rn), [dn] "=&v"(dn), [sp] "+v"(sp), [cur] "+v"(cur)
+        : [d1] "v"(d1), [d2] "v"(d2), [r1] "v"(r1), [r2] "v"(r2), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE)
+        : "vcc", "scc", "v62", "v63", "memory");
+}
+
 template <bool COUNT, bool FIX>
 __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k_paths(DScene sc, DCamera cam, PathsArgs a) {
     __shared__ uint2 s_stack[PT_STACK][PT_BLOCK];
@@ -318,18 +401,23 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     float d1 = box_dist(p.o, p.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
                     float d2 = box_dist(p.o, p.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
                     int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
-                    bool first_is_1 = d1 < d2;
-                    int rn = first_is_1 ? r1 : r2, rf = first_is_1 ? r2 : r1;
-                    float dn = first_is_1 ? d1 : d2, df = first_is_1 ? d2 : d1;
-                    if (df < best) {
-                        PT_PUT(sp, rf, df);
-                        sp++;
-                    }
-                    if (dn < best) {
-                        cur = rn;
-                        if (COUNT && cur < 0) cn.pops++;
+                    // counting builds and waves with a lane at the spill area take the C++ tail
+                    if (!COUNT && __builtin_amdgcn_ballot_w64(sp >= PT_STACK) == 0ull) {
+                        pt_inner_tail_lds(d1, d2, r1, r2, stack_lds, best, sp, cur);
                     } else {
-                        PT_POP();
+                        bool first_is_1 = d1 < d2;
+                        int rn = first_is_1 ? r1 : r2, rf = first_is_1 ? r2 : r1;
+                        float dn = first_is_1 ? d1 : d2, df = first_is_1 ? d2 : d1;
+                        if (df < best) {
+                            PT_PUT(sp, rf, df);
+                            sp++;
+                        }
+                        if (dn < best) {
+                            cur = rn;
+                            if (COUNT && cur < 0) cn.pops++;
+                        } else {
+                            PT_POP();
+                        }
                     }
                 }
             } else {
@@ -350,7 +438,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         last = (rt_f2u(t0.w) & 1u) != 0u;
                         cur = ~(k + 1);
                     }
-                    if (last) {
+                    if (!COUNT && __builtin_amdgcn_ballot_w64(last && sp > PT_STACK) == 0ull) {
+                        pt_pop_lds(__builtin_amdgcn_ballot_w64(last), stack_lds, best, sp, cur);
+                    } else if (last) {
                         PT_POP();
                     }
                 }
