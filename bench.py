@@ -65,7 +65,7 @@ def algorithmic_lane_ops(c) -> float:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
@@ -216,8 +216,12 @@ def main() -> int:
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
+            # PMC bytes per frame of the profiled workload, scaled to this run's launches of the dominant kernel
             with open(tpath) as f:
-                traffic = json.load(f).get(names[dominant], {}).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            per_frame = tj.get(names[dominant], {}).get("hbm_bytes_per_frame")
+            if per_frame is not None and tj.get("_workload") == args.workload and not args.fix_invdir:
+                traffic = round(per_frame * args.steps / max(1, int(launches[dominant])))
         except Exception:
             traffic = None
 

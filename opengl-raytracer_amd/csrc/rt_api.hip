@@ -271,10 +271,10 @@ static DCamera make_dcamera(const rt_camera* cam, int width, int height) {
 }
 
 // Buffers of the persistent path kernel: sample staging for one batch and the stack spill area.
-// Frames rendered by one launch of the path kernel: PT_MAX_BATCH, fewer for very large images so that the staged
-// samples (16 bytes per pixel and frame) stay within 2 GiB.
+// Frames rendered by one launch of the path kernel: PT_MAX_BATCH, fewer for large images so that the staged
+// samples (16 bytes per pixel and frame) stay within 4 GiB.
 static uint32_t paths_batch(size_t pixels) {
-    const size_t fit = ((size_t)2 << 30) / (pixels * sizeof(float4));
+    const size_t fit = ((size_t)4 << 30) / (pixels * sizeof(float4));
     return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
 }
 

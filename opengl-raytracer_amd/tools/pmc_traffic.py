@@ -8,7 +8,10 @@ doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  The path kernels issue 1
 not streaming), for which the factor is uncalibrated: the raw value is kept next to the corrected one.
 Infinity-Cache hits are counted as traffic by these counters, so the number is an upper bound on HBM bytes.
 
-usage: pmc_traffic.py <gpurun_out/prof_TAG> <frames per launch> [out.json]
+The figures are stored per launch of the profiled run and per frame (bench.py scales the latter to the launches of its
+own run); they describe the workload the profile was taken on, named in "_workload".
+
+usage: pmc_traffic.py <gpurun_out/prof_TAG> <frames per launch> [out.json] [workload]
 """
 import collections
 import csv
@@ -33,7 +36,8 @@ def main():
                 for key, cls in CLASS.items():
                     if key in row["Kernel_Name"]:
                         vals[cls][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    res = {"_source": os.path.basename(d.rstrip("/")), "_frames_per_launch": frames,
+    workload = sys.argv[4] if len(sys.argv) > 4 else "dragon80k_1080p"
+    res = {"_source": os.path.basename(d.rstrip("/")), "_frames_per_launch": frames, "_workload": workload,
            "_formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, largest launches only"}
     for cls, c in vals.items():
         # launches of the warm-up may be shorter: keep the launches with the largest write volume
@@ -41,7 +45,8 @@ def main():
         fk, wk = f[len(f) // 2:], w[len(w) // 2:]
         fetch, write = sum(fk) / len(fk), sum(wk) / len(wk)
         res[cls] = {"fetch_kib_raw": round(fetch, 1), "write_kib": round(write, 1),
-                    "hbm_bytes_per_launch": round((2 * fetch + write) * 1024)}
+                    "hbm_bytes_per_launch": round((2 * fetch + write) * 1024),
+                    "hbm_bytes_per_frame": round((2 * fetch + write) * 1024 / frames)}
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))

@@ -406,10 +406,10 @@ def test_band_argument_errors(pkg, gpu_ctx, scenes):
 
 
 def test_large_image_uses_smaller_batches(pkg, gpu_ctx, scenes):
-    """At 8192x4096 the staged samples of 8 frames would take 4.3 GB; the library renders fewer frames per launch
-    (2 GiB of staging at most).  Rendering 5 frames in one call must equal five single-frame dispatches bit for bit.
-    A taller image is rendered first: it stages 3 frames of 655 MB, less than the 4 x 537 MB the second image needs, so
-    the staging area has to grow although the pixel count shrinks."""
+    """At 8192x4096 the staged samples of 32 frames would take 17 GB; the library renders fewer frames per launch
+    (4 GiB of staging at most, 8 frames here).  Rendering 10 frames in one call (two launches) must equal ten
+    single-frame dispatches bit for bit.  A taller image is rendered first: it stages 6 frames of 655 MB, less than the
+    8 x 537 MB the second image needs, so the staging area has to grow although the pixel count shrinks."""
     gpu_ctx.upload_scene(scenes("teapot"))
     cam = pkg.make_camera()
     tall = pkg.DeviceBuffer(8192 * 5000 * 16)
@@ -419,8 +419,8 @@ def test_large_image_uses_smaller_batches(pkg, gpu_ctx, scenes):
     W, H = 8192, 4096
     nbytes = W * H * 16
     a, b = pkg.DeviceBuffer(nbytes), pkg.DeviceBuffer(nbytes)
-    gpu_ctx.render_device(cam, pkg.make_params(W, H, frames=5), a.ptr)
-    for f in range(5):
+    gpu_ctx.render_device(cam, pkg.make_params(W, H, frames=10), a.ptr)
+    for f in range(10):
         gpu_ctx.raytrace_frame(cam, pkg.make_params(W, H), f, b.ptr, b.ptr)
     gpu_ctx.synchronize()
     img_a = a.to_array((H, W, 4), np.float32)
