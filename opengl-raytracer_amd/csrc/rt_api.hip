@@ -28,6 +28,9 @@
 
 #define RT_BFS_PREFIX 1500    // inner-node records laid out breadth-first at the front (PT_CACHE of them are staged in LDS)
 #define RT_MAX_DEPTH 126      // deepest tree accepted (the reference's own stack holds 128 entries)
+#ifndef RT_LANES
+#define RT_LANES 2            // internal streams that single-frame calls rotate over (2, 4 and 6 measure the same, 3 is slower)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -95,8 +98,15 @@ struct rt_context {
     int cache_recs = 0;           // inner-node records that are laid out breadth-first at the front
     float4* d_samples = nullptr;  // [frames of one launch][pixels] staging
     size_t samples_bytes = 0;
-    uint2* d_pspill = nullptr;
+    uint2* d_pspill = nullptr;    // stack spill area, one copy per pipeline slot
     size_t pspill_entries = 0;
+    // Single-frame calls (rt_raytrace_frame) are pipelined: the path kernels of consecutive frames rotate over RT_LANES
+    // internal streams, so that the next frames fill the chip while the last long paths of a frame drain; only the accumulate kernels,
+    // which carry the frame-to-frame dependency, are ordered on the context's stream.
+    hipStream_t lane_stream[RT_LANES] = {};
+    hipEvent_t lane_done[RT_LANES] = {};   // recorded on lane_stream[k] after its path kernel
+    hipEvent_t slot_free[RT_LANES] = {};   // recorded on the context's stream after the accumulate that read slot k
+    uint32_t lane_next = 0;
 
     unsigned long long* d_counters = nullptr;
 
@@ -281,7 +291,8 @@ static uint32_t paths_batch(size_t pixels) {
 static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
     // sized in bytes: a smaller image may render more frames per launch than the one the buffer was made for
-    const size_t want_bytes = (size_t)paths_batch(pixels) * pixels * sizeof(float4);
+    const uint32_t batch = paths_batch(pixels);
+    const size_t want_bytes = (size_t)(batch < RT_LANES ? RT_LANES : batch) * pixels * sizeof(float4);  // one slot per lane for single-frame calls
     if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries) return RT_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (want_bytes > c->samples_bytes) {
@@ -293,7 +304,7 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     if (want_spill > c->pspill_entries) {
         dfree(c->d_pspill);
         c->pspill_entries = 0;
-        HIPCHK(c, hipMalloc(&c->d_pspill, want_spill * (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK * sizeof(uint2)));
+        HIPCHK(c, hipMalloc(&c->d_pspill, RT_LANES * want_spill * (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK * sizeof(uint2)));
         c->pspill_entries = want_spill;
     }
     return RT_OK;
@@ -347,15 +358,21 @@ static BandLayout band_layout(const rt_params* p) {
 }
 
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
-// them, in order, into out (reading prev).
+// them, in order, into out (reading prev).  pipelined: the call is one frame of a frame-by-frame loop; its path
+// kernel goes to an internal stream (see rt_context::lane_stream), its accumulate kernel to the context's stream.
 static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
-                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out) {
+                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined) {
     const bool sum = (p->flags & RT_FLAG_SUM) != 0;
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     size_t pixels = (size_t)p->width * p->height;
     int rc = ensure_paths_buffers(c, pixels);
     if (rc != RT_OK) return rc;
+    // counters and per-kernel timing are read on the context's stream: such calls stay on it
+    if (count || c->profiling || nframes != 1) pipelined = false;
+    const uint32_t slot = pipelined ? (c->lane_next++ % RT_LANES) : 0u;
+    hipStream_t pst = pipelined ? c->lane_stream[slot] : c->stream;
+    const size_t spill_threads = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
     PathsArgs a;
     a.frame_base = frame_base;
     a.frame_stride = stride;
@@ -379,28 +396,46 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) a.min_trav = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) a.min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }
-    a.samples = c->d_samples;
-    a.spill = c->d_pspill;
-    a.spill_stride = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
+    // slot k of the staging area is frame k of a batch; a pipelined frame uses slot `slot` and that slot's spill copy
+    a.samples = c->d_samples + (size_t)slot * pixels;
+    a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * spill_threads : nullptr;
+    a.spill_stride = spill_threads;
     a.counters = count ? c->d_counters : nullptr;
     dim3 grid(c->num_cus * PT_BLOCKS_PER_CU), blk(PT_BLOCK);
+    if (pipelined) {
+        // the slot's previous reader (an accumulate on the context's stream) must have finished
+        HIPCHK(c, hipStreamWaitEvent(pst, c->slot_free[slot], 0));
+    } else {
+        // a batch uses every slot and the first spill copy: wait for the internal streams' kernels
+        for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamWaitEvent(pst, c->lane_done[k], 0));
+    }
     {
         LaunchTimer lt(c, RT_K_PATHS);
-#define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, c->stream, c->sc, dc, a)
+#define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, pst, c->sc, dc, a)
         if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
         else { if (fix) PATHS(false, true); else PATHS(false, false); }
 #undef PATHS
     }
     HIPCHK(c, hipGetLastError());
+    if (pipelined) {
+        HIPCHK(c, hipEventRecord(c->lane_done[slot], pst));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[slot], 0));
+    }
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
         uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
         if (bl.px.num_pixels)
             hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((bl.px.num_pixels + 255) / 256)), dim3(256), 0, c->stream,
-                               (const float4*)c->d_samples, nframes, (uint32_t)pixels, bl.px, frame_base, stride,
+                               (const float4*)a.samples, nframes, (uint32_t)pixels, bl.px, frame_base, stride,
                                sum ? 1u : 0u, read_prev, prev, out);
     }
     HIPCHK(c, hipGetLastError());
+    // the staging slots this call used are free again once its accumulate has run
+    if (pipelined) {
+        HIPCHK(c, hipEventRecord(c->slot_free[slot], c->stream));
+    } else {
+        for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipEventRecord(c->slot_free[k], c->stream));
+    }
     return RT_OK;
 }
 
@@ -430,6 +465,15 @@ int rt_create(int device_id, rt_context** out_ctx) {
         return rc;
     }
     c->stream = c->own_stream;
+    for (int k = 0; k < RT_LANES; k++) {
+        if ((e = hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming)) != hipSuccess) {
+            int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
+            rt_destroy(c);
+            return rc;
+        }
+    }
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
@@ -444,6 +488,14 @@ int rt_destroy(rt_context* c) {
     if (!c) return RT_EINVAL;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < RT_LANES; k++) {
+        if (c->lane_stream[k]) {
+            (void)hipStreamSynchronize(c->lane_stream[k]);
+            (void)hipStreamDestroy(c->lane_stream[k]);
+        }
+        if (c->lane_done[k]) (void)hipEventDestroy(c->lane_done[k]);
+        if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
+    }
     free_scene(c);
     free_buffers(c);
     for (void* p : c->ws_ptr)
@@ -989,7 +1041,7 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
     if (!mega && !wavefront)
-        return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame);
+        return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame, true);
     if ((rc = ensure_buffers(c, p->width, p->height)) != RT_OK) return rc;
 
     FrameArgs fa;
@@ -1079,7 +1131,7 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     const uint32_t batch = paths_batch((size_t)p->width * p->height);
     for (uint32_t f = 0; f < p->frames; f += batch) {
         uint32_t n = p->frames - f < batch ? p->frames - f : batch;
-        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum);
+        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, false);
         if (rc != RT_OK) return rc;
     }
     return RT_OK;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fix-invdir", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="time rt_primary_hits instead of full frames")
     ap.add_argument("--counters", action="store_true", help="render with RT_FLAG_COUNTERS and print the work counters")
+    ap.add_argument("--per-frame", action="store_true", help="one rt_raytrace_frame call per frame (ping-pong buffers), as the reference's loop does")
     ap.add_argument("--bands", type=int, default=0, help="time every band of an N-way tile partition on this one GPU")
     a = ap.parse_args()
     pkg = entry.load_package()
@@ -68,6 +69,22 @@ def main():
                 ms.append(best)
             print(f"{a.bands} {'interleaved' if inter else 'contiguous'} bands, ms per frame per band: "
                   + " ".join(f"{x:.3f}" for x in ms) + f" | max {max(ms):.3f} mean {sum(ms) / len(ms):.3f} balance {sum(ms) / len(ms) / max(ms):.2f}")
+        ctx.close()
+        return
+    if a.per_frame:
+        nbytes = a.width * a.height * 16
+        bufs = [pkg.DeviceBuffer(nbytes), pkg.DeviceBuffer(nbytes)]
+        p1 = pkg.make_params(a.width, a.height, flags=flags)
+        for phase, n in (("warm-up", a.warmup), ("timed", a.frames)):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for f in range(n):
+                ctx.raytrace_frame(cam, p1, f, bufs[(f + 1) & 1].ptr, bufs[f & 1].ptr)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+        print(f"{a.pipeline} {a.scene} {a.width}x{a.height}: {dt / a.frames * 1e3:.3f} ms per frame over {a.frames} single-frame calls")
+        for b in bufs:
+            b.free()
         ctx.close()
         return
     ctx.render(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags), img)

@@ -165,6 +165,39 @@ def test_resume_accumulation_equals_one_shot(pkg, gpu_ctx, scenes):
     assert np.array_equal(bits(one), bits(part))
 
 
+def test_single_frame_calls_pipeline_and_mix_with_batches(pkg, oracle, gpu_ctx, scenes):
+    """rt_raytrace_frame calls are pipelined inside the library (the path kernels of consecutive frames overlap on
+    internal streams).  A frame-by-frame loop, a batched call in the middle of it, a scene swap and a counting call must
+    all see each other's results: the final image equals the oracle's running mean of the same frames bit for bit."""
+    W, H = 320, 180
+    cam = pkg.make_camera()
+    teapot, dragon = scenes("teapot"), scenes("dragon80k")
+    bufs = [pkg.DeviceBuffer(W * H * 16), pkg.DeviceBuffer(W * H * 16)]
+    p1 = pkg.make_params(W, H)
+    for scene in (teapot, dragon, teapot):
+        gpu_ctx.upload_scene(scene)
+        f = 0
+        for _ in range(5):                                  # frames 0..4, one call each
+            gpu_ctx.raytrace_frame(cam, p1, f, bufs[(f + 1) & 1].ptr, bufs[f & 1].ptr)
+            f += 1
+        last = bufs[(f - 1) & 1]
+        gpu_ctx.render_device(cam, pkg.make_params(W, H, frames=4, frame_base=f), last.ptr)   # frames 5..8 batched, in place
+        f += 4
+        other = bufs[0] if last is bufs[1] else bufs[1]
+        gpu_ctx.raytrace_frame(cam, pkg.make_params(W, H, flags=pkg.RT_FLAG_COUNTERS), f, last.ptr, other.ptr)  # frame 9, counting
+        f += 1
+        for _ in range(3):                                  # frames 10..12
+            src, dst = (other, last) if (f & 1) == 0 else (last, other)
+            gpu_ctx.raytrace_frame(cam, p1, f, src.ptr, dst.ptr)
+            f += 1
+        gpu_ctx.synchronize()
+        got = dst.to_array((H, W, 4), np.float32)
+        want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=f))
+        assert np.array_equal(bits(got), bits(want))
+    for b in bufs:
+        b.free()
+
+
 def test_sample_partition_sum_matches_running_mean(pkg, gpu_ctx, scenes):
     """The multi-GPU decomposition on one GPU: G interleaved frame subsets summed, divided by the frame
     count, against the sequential running mean -- equal to fp32 rounding, far inside 1e-3."""
