@@ -382,7 +382,8 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     a.tiles_x = (p->width + 7) / 8;
     a.tile_y0 = bl.tile_y0;
     a.stripe_period = bl.stripe_period;
-    a.tiles_per_frame = a.tiles_x * bl.tile_rows;
+    a.strip_tiles = PT_STRIP_W * bl.tile_rows;
+    a.tiles_per_frame = ((a.tiles_x + PT_STRIP_W - 1) / PT_STRIP_W) * a.strip_tiles;
     a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
     a.pixels = (uint32_t)pixels;
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;

@@ -44,8 +44,13 @@
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
 #define PT_W_INNER 4           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
 #define PT_W_LEAF 7            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
+#ifndef PT_MAX_BATCH
 #define PT_MAX_BATCH 32        // frames per launch: the drain at the end of a launch (a few long paths keep their waves alive,
                                // ~0.36 ms on dragon80k) is paid once per launch, so more frames per launch amortise it
+#endif
+#ifndef PT_STRIP_W
+#define PT_STRIP_W 16          // tile columns per vertical strip of the tile numbering (the last strip may stick out of the image)
+#endif
 #define PT_STRIPE_TILES 2      // interleaved bands: a stripe is 2 tile rows = 16 pixel rows
 
 enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
@@ -53,7 +58,8 @@ enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
 struct PathsArgs {
     uint32_t frame_base, frame_stride, num_frames;
     uint32_t bounces;
-    int tiles_x, tiles_per_frame;   // 8x8 pixel tiles (of the band being rendered)
+    int tiles_x, tiles_per_frame;   // 8x8 pixel tiles (of the band being rendered); tiles_per_frame counts whole strips
+    int strip_tiles;                // tiles in one vertical strip: PT_STRIP_W * tile rows of the band
     int tile_y0;                    // first tile row of the band (contiguous band) or of its first stripe (interleaved)
     int stripe_period;              // 0: contiguous band; else tile rows between two stripes of the band (PT_STRIPE_TILES * bands)
     uint32_t total_tiles;           // num_frames * tiles_per_frame
@@ -221,6 +227,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             e_ = spill_load(spill + (size_t)((i_)-PT_STACK) * spill_stride); \
     } while (0)
 
+    // Workgroups are dealt to the 8 XCDs round-robin by index.  Every round of gridDim.x work items is split into 8
+    // consecutive runs, one per XCD, so that the (tile, frame) items an XCD works on at one time are neighbours and its
+    // L2 holds one part of the scene instead of a copy of all of it.
+    const uint32_t xcd_slot = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     // wave-uniform cursor into the tile pool
     uint32_t tile_g = 0;
     int tile_off = 64;
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     uint32_t k = 0;
                     if ((tid & 63) == 0) k = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                    tile_g = blockIdx.x + k * gridDim.x;
+                    tile_g = xcd_slot + k * gridDim.x;
                     tile_off = 0;
                     if (tile_g >= a.total_tiles) exhausted = true;
                 }
@@ -284,9 +294,15 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     int avail = 64 - tile_off;
                     if (state == ST_NEED && rank < avail) {
                         int l = tile_off + rank;
-                        uint32_t f = tile_g / (uint32_t)a.tiles_per_frame;
-                        int t = (int)(tile_g - f * (uint32_t)a.tiles_per_frame);
-                        int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                        // the frames of a launch share the camera: tile t of every frame is handed out before tile t+1 of
+                        // any, so the waves that run at one time walk the same part of the BVH
+                        const uint32_t tq = tile_g / a.num_frames;
+                        const uint32_t f = tile_g - tq * a.num_frames;
+                        const int t = (int)tq;
+                        // tiles are numbered strip by strip (PT_STRIP_W tile columns wide, row-major inside), so that the
+                        // tiles the chip works on at one time form a compact block of the image, not a full-width band
+                        const int strip = t / a.strip_tiles, r = t - strip * a.strip_tiles;
+                        const int ty = r / PT_STRIP_W, tx = strip * PT_STRIP_W + r % PT_STRIP_W;
                         // tile row of the band -> tile row of the image
                         const int gty = a.stripe_period ? (ty / PT_STRIPE_TILES) * a.stripe_period + (ty % PT_STRIPE_TILES) + a.tile_y0
                                                         : ty + a.tile_y0;
