@@ -1,9 +1,10 @@
 // Persistent path kernel: the default pipeline of the render path on MI355X.
 //
 // One launch renders a BATCH of frames.  The grid is two 1024-thread workgroups per CU (32 waves, 8 per SIMD); every
-// wave is an independent worker that keeps its 64 lanes busy with paths drawn from a pool of (frame, 8x8 pixel tile)
+// wave is an independent worker that keeps its 64 lanes busy with paths drawn from a pool of (8x8 pixel tile, frame)
 // items, so that lanes whose path has ended (60 % of primary rays leave the scene at once) do not idle while
-// their neighbours traverse.  Each wave alternates two phases, each of which runs one kind of code on as many
+// their neighbours traverse.  The items are numbered tile-major, frame-minor: the frames of a launch share the camera,
+// so the waves that run at one time walk the same part of the BVH and a scene far larger than the L2 stays in it.  Each wave alternates two phases, each of which runs one kind of code on as many
 // lanes as possible:
 //
 //   service   shade the lanes whose traversal has finished (bounce + Russian roulette, or the sample store),
