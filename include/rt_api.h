@@ -170,7 +170,10 @@ int rt_get_built_links(rt_context* ctx, int32_t* links);
  * ...) (raytrace.h:10) with image unit 6 = d_prev_frame (read) and unit 5 = d_out_frame
  * (written) (main.cpp:189-192).  Both are DEVICE pointers to W*H*4 floats and may alias.
  * d_prev_frame may be NULL when frame_count == 0 (treated as zeros).  Uses params->width,
- * height, rays_per_pixel, ray_bounces, render_mode, flags; asynchronous. */
+ * height, rays_per_pixel, ray_bounces, render_mode, flags; asynchronous.
+ * Consecutive calls overlap on the GPU: the traversal of a frame runs on an internal stream and only the
+ * step that reads d_prev_frame and writes d_out_frame is ordered on the context's stream, which is all a
+ * caller can observe -- work enqueued on that stream after the call sees the finished frame. */
 int rt_raytrace_frame(rt_context* ctx, const rt_camera* cam, const rt_params* params,
                       uint32_t frame_count, const float* d_prev_frame, float* d_out_frame);
 
