@@ -176,6 +176,53 @@ def test_small_subtree_kernel_builds_the_same_tree_as_the_level_loop(pkg, name):
         assert np.array_equal(faces1, faces2), variant
 
 
+def test_pipelined_frames_between_rebuilds_and_refits(pkg):
+    """A dynamic-scene loop: every step moves the vertices, rebuilds or refits the tree and renders two single frames.
+    Single-frame calls overlap on internal streams; a rebuild overwrites the scene buffers those kernels read.  The
+    whole sequence must give the same pixels as the same sequence run with per-kernel timing switched on, which keeps
+    every kernel on the context's stream (no overlap)."""
+    v, f = _read_obj(pkg, "dragon80k")
+    col = pkg.make_colours(9, f.shape[0])
+    cam = pkg.make_camera(pos=CAMS["dragon80k"])
+    W, H = 640, 360
+    rng = np.random.RandomState(11)
+    moves = [(v + rng.normal(0.0, 0.01, v.shape)).astype(np.float32) for _ in range(6)]
+
+    def run(serial: bool):
+        ctx = pkg.RenderContext(0)
+        ctx.build_scene_device(v, f, col, download=False)
+        ctx.set_profiling(serial)
+        bufs = [pkg.DeviceBuffer(W * H * 16), pkg.DeviceBuffer(W * H * 16)]
+        d_moves = [pkg.DeviceBuffer.from_array(m) for m in moves]      # resident: no copy (and no implicit sync) per step
+        sums = []
+        for step in range(12):
+            d_v = d_moves[step % len(d_moves)]
+            if step % 3 == 2:
+                ctx.refit_scene_device(d_v.ptr)
+            else:
+                ctx.rebuild_scene_device(d_v.ptr)
+            p1 = pkg.make_params(W, H)
+            ctx.raytrace_frame(cam, p1, 0, 0, bufs[0].ptr)
+            ctx.raytrace_frame(cam, p1, 1, bufs[0].ptr, bufs[1].ptr)
+            if step % 4 == 3:                                              # no synchronisation on the other steps
+                ctx.synchronize()
+                sums.append(bufs[1].to_array((H, W, 4), np.float32).copy())
+        ctx.synchronize()
+        sums.append(bufs[1].to_array((H, W, 4), np.float32).copy())
+        if serial:
+            ctx.kernel_times()
+        for b in bufs + d_moves:
+            b.free()
+        ctx.close()
+        return sums
+
+    a, b = run(False), run(True)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(bits(x), bits(y))
+        assert x[..., :3].max() > 0.0
+
+
 def test_rebuild_from_device_vertices(pkg, oracle):
     """rt_rebuild_scene_device: same topology, new vertex positions from a device pointer; per-tree parity with the
     oracle, and the same tree as a fresh build from host memory."""
