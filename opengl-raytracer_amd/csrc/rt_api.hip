@@ -100,8 +100,9 @@ struct rt_context {
     size_t samples_bytes = 0;
     uint2* d_pspill = nullptr;    // stack spill area, one copy per pipeline slot
     size_t pspill_entries = 0;
-    // Single-frame calls (rt_raytrace_frame) are pipelined: the path kernels of consecutive frames rotate over RT_LANES
-    // internal streams, so that the next frames fill the chip while the last long paths of a frame drain; only the accumulate kernels,
+    // Launches of the path kernel are pipelined: consecutive launches (the frames of a frame-by-frame loop, the batches
+    // of a multi-frame call) rotate over RT_LANES internal streams, so that the next one fills the chip while the last
+    // long paths of a launch drain; only the accumulate kernels,
     // which carry the frame-to-frame dependency, are ordered on the context's stream.
     hipStream_t lane_stream[RT_LANES] = {};
     hipEvent_t lane_done[RT_LANES] = {};   // recorded on lane_stream[k] after its path kernel
@@ -282,9 +283,9 @@ static DCamera make_dcamera(const rt_camera* cam, int width, int height) {
 
 // Buffers of the persistent path kernel: sample staging for one batch and the stack spill area.
 // Frames rendered by one launch of the path kernel: PT_MAX_BATCH, fewer for large images so that the staged
-// samples (16 bytes per pixel and frame) stay within 4 GiB.
+// samples (16 bytes per pixel and frame, one slot of that many frames per internal stream) stay within 4 GiB.
 static uint32_t paths_batch(size_t pixels) {
-    const size_t fit = ((size_t)4 << 30) / (pixels * sizeof(float4));
+    const size_t fit = ((size_t)4 << 30) / RT_LANES / (pixels * sizeof(float4));
     return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
 }
 
@@ -292,7 +293,7 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
     // sized in bytes: a smaller image may render more frames per launch than the one the buffer was made for
     const uint32_t batch = paths_batch(pixels);
-    const size_t want_bytes = (size_t)(batch < RT_LANES ? RT_LANES : batch) * pixels * sizeof(float4);  // one slot per lane for single-frame calls
+    const size_t want_bytes = (size_t)RT_LANES * batch * pixels * sizeof(float4);  // one slot of `batch` frames per lane
     if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries) return RT_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (want_bytes > c->samples_bytes) {
@@ -358,8 +359,9 @@ static BandLayout band_layout(const rt_params* p) {
 }
 
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
-// them, in order, into out (reading prev).  pipelined: the call is one frame of a frame-by-frame loop; its path
-// kernel goes to an internal stream (see rt_context::lane_stream), its accumulate kernel to the context's stream.
+// them, in order, into out (reading prev).  pipelined: the path kernel goes to one of the internal streams in turn
+// (see rt_context::lane_stream) and overlaps with the previous launch's; the accumulate kernel, which carries the
+// frame-to-frame dependency, goes to the context's stream.
 static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
                               uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined) {
     const bool sum = (p->flags & RT_FLAG_SUM) != 0;
@@ -369,7 +371,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     int rc = ensure_paths_buffers(c, pixels);
     if (rc != RT_OK) return rc;
     // counters and per-kernel timing are read on the context's stream: such calls stay on it
-    if (count || c->profiling || nframes != 1) pipelined = false;
+    if (count || c->profiling) pipelined = false;
     const uint32_t slot = pipelined ? (c->lane_next++ % RT_LANES) : 0u;
     hipStream_t pst = pipelined ? c->lane_stream[slot] : c->stream;
     const size_t spill_threads = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
@@ -397,8 +399,8 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) a.min_trav = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) a.min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }
-    // slot k of the staging area is frame k of a batch; a pipelined frame uses slot `slot` and that slot's spill copy
-    a.samples = c->d_samples + (size_t)slot * pixels;
+    // every internal stream has its own slot of the staging area (paths_batch frames) and its own spill copy
+    a.samples = c->d_samples + (size_t)slot * paths_batch(pixels) * pixels;
     a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * spill_threads : nullptr;
     a.spill_stride = spill_threads;
     a.counters = count ? c->d_counters : nullptr;
@@ -407,7 +409,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
         // the slot's previous reader (an accumulate on the context's stream) must have finished
         HIPCHK(c, hipStreamWaitEvent(pst, c->slot_free[slot], 0));
     } else {
-        // a batch uses every slot and the first spill copy: wait for the internal streams' kernels
+        // slot 0 and the first spill copy may still be in use by an internal stream's kernel
         for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamWaitEvent(pst, c->lane_done[k], 0));
     }
     {
@@ -1132,7 +1134,7 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     const uint32_t batch = paths_batch((size_t)p->width * p->height);
     for (uint32_t f = 0; f < p->frames; f += batch) {
         uint32_t n = p->frames - f < batch ? p->frames - f : batch;
-        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, false);
+        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, true);
         if (rc != RT_OK) return rc;
     }
     return RT_OK;

@@ -45,13 +45,9 @@
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
 #define PT_W_INNER 4           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
 #define PT_W_LEAF 7            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
-#ifndef PT_MAX_BATCH
-#define PT_MAX_BATCH 32        // frames per launch: the drain at the end of a launch (a few long paths keep their waves alive,
-                               // ~0.36 ms on dragon80k) is paid once per launch, so more frames per launch amortise it
-#endif
-#ifndef PT_STRIP_W
+#define PT_MAX_BATCH 16        // frames per launch.  The end of a launch drains slowly (a few long paths keep their waves
+                               // alive, ~0.3 ms on dragon80k); consecutive launches of a call overlap on two streams to hide it
 #define PT_STRIP_W 16          // tile columns per vertical strip of the tile numbering (the last strip may stick out of the image)
-#endif
 #define PT_STRIPE_TILES 2      // interleaved bands: a stripe is 2 tile rows = 16 pixel rows
 
 enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };

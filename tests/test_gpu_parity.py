@@ -439,14 +439,15 @@ def test_band_argument_errors(pkg, gpu_ctx, scenes):
 
 
 def test_large_image_uses_smaller_batches(pkg, gpu_ctx, scenes):
-    """At 8192x4096 the staged samples of 32 frames would take 17 GB; the library renders fewer frames per launch
-    (4 GiB of staging at most, 8 frames here).  Rendering 10 frames in one call (two launches) must equal ten
-    single-frame dispatches bit for bit.  A taller image is rendered first: it stages 6 frames of 655 MB, less than the
-    8 x 537 MB the second image needs, so the staging area has to grow although the pixel count shrinks."""
+    """At 8192x4096 the staged samples of 16 frames would take 8.6 GB; the library renders fewer frames per launch
+    (4 GiB of staging at most, shared by two overlapping launches: 3 frames each here).  Rendering 10 frames in one call
+    (four launches) must equal ten single-frame dispatches bit for bit.  A taller image is rendered first: it stages
+    2 x 2 frames of 786 MB, less than the 2 x 3 x 537 MB the second image needs, so the staging area has to grow
+    although the pixel count shrinks."""
     gpu_ctx.upload_scene(scenes("teapot"))
     cam = pkg.make_camera()
-    tall = pkg.DeviceBuffer(8192 * 5000 * 16)
-    gpu_ctx.render_device(cam, pkg.make_params(8192, 5000, frames=3), tall.ptr)
+    tall = pkg.DeviceBuffer(8192 * 6000 * 16)
+    gpu_ctx.render_device(cam, pkg.make_params(8192, 6000, frames=3), tall.ptr)
     gpu_ctx.synchronize()
     tall.free()
     W, H = 8192, 4096
