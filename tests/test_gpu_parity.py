@@ -165,6 +165,27 @@ def test_resume_accumulation_equals_one_shot(pkg, gpu_ctx, scenes):
     assert np.array_equal(bits(one), bits(part))
 
 
+@pytest.mark.parametrize("name", ["teapot", "model", "dragon80k"])
+def test_gpu_against_committed_golden_vectors(pkg, gpu_ctx, scenes, name):
+    """The HIP path against the committed fixtures directly (tests/golden/oracle_*.npz, written by make_golden.py): primary
+    hit ids and distances, three accumulated frames with their work counters, two frames with RT_FLAG_FIX_INVDIR."""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"))
+    w, h = [int(x) for x in g["size"]]
+    cam = pkg.make_camera(pos=tuple(float(x) for x in g["pos"]))
+    gpu_ctx.upload_scene(scenes(name))
+    ids, t = gpu_ctx.primary_hits(cam, w, h)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(t), bits(g["t"]))
+    for frames, extra, key_img, key_cnt in ((3, 0, "img", "counters"), (2, pkg.RT_FLAG_FIX_INVDIR, "img_fix", "counters_fix")):
+        gpu_ctx.reset_counters()
+        img = gpu_ctx.render(cam, pkg.make_params(w, h, frames=frames, flags=extra | pkg.RT_FLAG_COUNTERS))
+        assert np.array_equal(bits(img), bits(g[key_img]))
+        assert np.array_equal(gpu_ctx.counters(), g[key_cnt])
+        plain = gpu_ctx.render(cam, pkg.make_params(w, h, frames=frames, flags=extra))   # the non-counting kernels
+        assert np.array_equal(bits(plain), bits(g[key_img]))
+
+
 def test_single_frame_calls_pipeline_and_mix_with_batches(pkg, oracle, gpu_ctx, scenes):
     """rt_raytrace_frame calls are pipelined inside the library (the path kernels of consecutive frames overlap on
     internal streams).  A frame-by-frame loop, a batched call in the middle of it, a scene swap and a counting call must
