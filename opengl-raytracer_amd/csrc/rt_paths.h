@@ -41,6 +41,9 @@
 #define PT_STACK 8             // traversal-stack entries per lane kept in LDS
 #define PT_CACHE 254           // inner-node records staged in LDS (64 B each); 2 x (stacks+cache+counter) <= 160 KiB
 #endif
+// log2 of the distance in bytes between two stack slots of a lane (PT_BLOCK entries of 8 bytes)
+#define PT_SLOT_SHIFT (PT_BLOCK == 1024 ? 13 : PT_BLOCK == 512 ? 12 : PT_BLOCK == 256 ? 11 : -1)
+static_assert(PT_SLOT_SHIFT > 0 && (1 << PT_SLOT_SHIFT) == PT_BLOCK * 8, "PT_BLOCK must be 256, 512 or 1024");
 #define PT_MIN_TRAV 40         // leave the traversal phase when fewer lanes than this still traverse ...
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
 #define PT_W_INNER 4           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
@@ -118,7 +121,7 @@ __device__ __forceinline__ void pt_pop_lds(unsigned long long need, uint32_t sta
         "s_cbranch_scc0 Lpop_done%=\n\t"
         "s_mov_b64 exec, %[np]\n\t"
         "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
-        "v_lshl_add_u32 %[addr], %[sp], 13, %[stack0]\n\t"
+        "v_lshl_add_u32 %[addr], %[sp], %[shift], %[stack0]\n\t"
         "ds_read_b64 v[62:63], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_cmp_nge_f32_e32 vcc, v63, %[best]\n\t"
@@ -128,7 +131,7 @@ __device__ __forceinline__ void pt_pop_lds(unsigned long long need, uint32_t sta
         "Lpop_done%=:\n\t"
         "s_mov_b64 exec, %[save]"
         : [save] "=&s"(save), [np] "=&s"(np), [addr] "=&v"(addr), [sp] "+v"(sp), [cur] "+v"(cur)
-        : [need] "s"(need), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE)
+        : [need] "s"(need), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE), [shift] "n"(PT_SLOT_SHIFT)
         : "vcc", "scc", "v62", "v63", "memory");
 }
 
@@ -149,7 +152,7 @@ __device__ __forceinline__ void pt_inner_tail_lds(float d1, float d2, int r1, in
         "v_cndmask_b32_e32 %[dn], %[d2], %[d1], vcc\n\t"
         "v_cmp_lt_f32_e32 vcc, v63, %[best]\n\t"
         "s_and_b64 exec, %[save], vcc\n\t"
-        "v_lshl_add_u32 %[addr], %[sp], 13, %[stack0]\n\t"
+        "v_lshl_add_u32 %[addr], %[sp], %[shift], %[stack0]\n\t"
         "ds_write_b64 %[addr], v[62:63]\n\t"
         "v_add_u32_e32 %[sp], 1, %[sp]\n\t"
         "s_mov_b64 exec, %[save]\n\t"
@@ -165,7 +168,7 @@ __device__ __forceinline__ void pt_inner_tail_lds(float d1, float d2, int r1, in
         "s_cbranch_scc0 Ltail_done%=\n\t"
         "s_mov_b64 exec, %[np]\n\t"
         "v_add_u32_e32 %[sp], -1, %[sp]\n\t"
-        "v_lshl_add_u32 %[addr], %[sp], 13, %[stack0]\n\t"
+        "v_lshl_add_u32 %[addr], %[sp], %[shift], %[stack0]\n\t"
         "ds_read_b64 v[62:63], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_cmp_nge_f32_e32 vcc, v63, %[best]\n\t"
@@ -175,7 +178,7 @@ __device__ __forceinline__ void pt_inner_tail_lds(float d1, float d2, int r1, in
         "Ltail_done%=:\n\t"
         "s_mov_b64 exec, %[save]"
         : [save] "=&s"(save), [np] "=&s"(np), [addr] "=&v"(addr), [rn] "=&v"(rn), [dn] "=&v"(dn), [sp] "+v"(sp), [cur] "+v"(cur)
-        : [d1] "v"(d1), [d2] "v"(d2), [r1] "v"(r1), [r2] "v"(r2), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE)
+        : [d1] "v"(d1), [d2] "v"(d2), [r1] "v"(r1), [r2] "v"(r2), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE), [shift] "n"(PT_SLOT_SHIFT)
         : "vcc", "scc", "v62", "v63", "memory");
 }
 
