@@ -109,6 +109,11 @@ struct rt_context {
     hipEvent_t slot_free[RT_LANES] = {};   // recorded on the context's stream after the accumulate that read slot k
     uint32_t lane_next = 0;
 
+    // scheduling parameters of the path kernel; the RT_TUNE_* environment variables (read once, at rt_create) override
+    // the defaults for tuning runs
+    int tune_min_trav = PT_MIN_TRAV, tune_min_service = PT_MIN_SERVICE, tune_w_inner = PT_W_INNER, tune_w_leaf = PT_W_LEAF;
+    int tune_cache = -1;  // >= 0: stage at most this many records in LDS
+
     unsigned long long* d_counters = nullptr;
 
     bool profiling = false;
@@ -389,16 +394,11 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
     a.pixels = (uint32_t)pixels;
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
-    a.min_trav = PT_MIN_TRAV;
-    a.min_service = PT_MIN_SERVICE;
-    // developer knobs for tuning runs
-    a.w_inner = PT_W_INNER;
-    a.w_leaf = PT_W_LEAF;
-    if (const char* e = getenv("RT_TUNE_W_INNER")) a.w_inner = atoi(e);
-    if (const char* e = getenv("RT_TUNE_W_LEAF")) a.w_leaf = atoi(e);
-    if (const char* e = getenv("RT_TUNE_MIN_TRAV")) a.min_trav = atoi(e);
-    if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) a.min_service = atoi(e);
-    if (const char* e = getenv("RT_TUNE_CACHE")) { int v = atoi(e); if (v < a.cache_recs) a.cache_recs = v; }
+    a.min_trav = c->tune_min_trav;
+    a.min_service = c->tune_min_service;
+    a.w_inner = c->tune_w_inner;
+    a.w_leaf = c->tune_w_leaf;
+    if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
     // every internal stream has its own slot of the staging area (paths_batch frames) and its own spill copy
     a.samples = c->d_samples + (size_t)slot * paths_batch(pixels) * pixels;
     a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * spill_threads : nullptr;
@@ -477,6 +477,11 @@ int rt_create(int device_id, rt_context** out_ctx) {
             return rc;
         }
     }
+    if (const char* e = getenv("RT_TUNE_W_INNER")) c->tune_w_inner = atoi(e);
+    if (const char* e = getenv("RT_TUNE_W_LEAF")) c->tune_w_leaf = atoi(e);
+    if (const char* e = getenv("RT_TUNE_MIN_TRAV")) c->tune_min_trav = atoi(e);
+    if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) c->tune_min_service = atoi(e);
+    if (const char* e = getenv("RT_TUNE_CACHE")) c->tune_cache = atoi(e);
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
