@@ -482,6 +482,13 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) c->tune_min_trav = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) c->tune_min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) c->tune_cache = atoi(e);
+    // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
+    // traverse while some wait for a refill would send the wave back and forth without progress
+    auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    c->tune_min_trav = clamp(c->tune_min_trav, 1, 48);
+    c->tune_min_service = clamp(c->tune_min_service, 1, 64);
+    c->tune_w_inner = clamp(c->tune_w_inner, 1, 64);
+    c->tune_w_leaf = clamp(c->tune_w_leaf, 1, 64);
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
