@@ -65,7 +65,7 @@ def algorithmic_lane_ops(c) -> float:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
