@@ -13,7 +13,8 @@ raytrace.glsl:245) in a separate untimed pass over exactly the timed frames.
 
 Besides the contract's fields the JSON line carries
   roofline      algorithmic bytes of the dominant kernel / its mean launch duration (HIP events on
-                the launch stream, separate profiled pass) against the 8 TB/s HBM peak
+                the launch stream, separate profiled pass in which launches run one at a time; in
+                the timed region the library overlaps consecutive launches) against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (a port of the reference's GLSL path) timed on this host's cores on a
                 bounded sample of the same workload
 """
