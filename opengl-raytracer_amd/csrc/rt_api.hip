@@ -288,7 +288,9 @@ static DCamera make_dcamera(const rt_camera* cam, int width, int height) {
 
 // Buffers of the persistent path kernel: sample staging for one batch and the stack spill area.
 // Frames rendered by one launch of the path kernel: PT_MAX_BATCH, fewer for large images so that the staged
-// samples (16 bytes per pixel and frame, one slot of that many frames per internal stream) stay within 4 GiB.
+// samples (16 bytes per pixel and frame, one slot of that many frames per internal stream) stay within 4 GiB -- except
+// that a launch holds at least one frame, so images above 2^27 pixels stage RT_LANES x 16 bytes per pixel (8 GiB at the
+// 16384 x 16384 limit).
 static uint32_t paths_batch(size_t pixels) {
     const size_t fit = ((size_t)4 << 30) / RT_LANES / (pixels * sizeof(float4));
     return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
@@ -326,7 +328,8 @@ struct BandLayout {
     std::vector<std::pair<uint32_t, uint32_t>> ranges;
 };
 
-static BandLayout band_layout(const rt_params* p) {
+// want_ranges = false leaves `ranges` empty (and allocates nothing).
+static BandLayout band_layout(const rt_params* p, bool want_ranges = true) {
     BandLayout b;
     const int H = p->height, W = p->width, R = (H + 7) / 8;
     const int idx = p->band ? (int)(p->band >> 16) : 0;
@@ -340,7 +343,7 @@ static BandLayout band_layout(const rt_params* p) {
         b.tile_rows = t1 - t0;
         b.px.row0 = (uint32_t)r0;
         b.px.num_pixels = (uint32_t)(r1 - r0) * (uint32_t)W;
-        if (r1 > r0) b.ranges.push_back({(uint32_t)r0, (uint32_t)(r1 - r0)});
+        if (r1 > r0 && want_ranges) b.ranges.push_back({(uint32_t)r0, (uint32_t)(r1 - r0)});
         return b;
     }
     const int U = PT_STRIPE_TILES;
@@ -355,12 +358,57 @@ static BandLayout band_layout(const rt_params* p) {
         const int r0 = t * 8, r1 = te * 8 < H ? te * 8 : H;
         b.tile_rows += te - t;
         if (r1 > r0) {
-            b.ranges.push_back({(uint32_t)r0, (uint32_t)(r1 - r0)});
+            if (want_ranges) b.ranges.push_back({(uint32_t)r0, (uint32_t)(r1 - r0)});
             rows += (uint32_t)(r1 - r0);
         }
     }
     b.px.num_pixels = rows * (uint32_t)W;
     return b;
+}
+
+// Launch arguments of the path kernel for `nframes` frames frame_base, frame_base+stride, ... of the band `bl`;
+// the caller adds the staging and spill pointers.
+static void fill_paths_args(const rt_context* c, const rt_params* p, const BandLayout& bl, uint32_t frame_base, uint32_t stride,
+                            uint32_t nframes, PathsArgs& a) {
+    a.frame_base = frame_base;
+    a.frame_stride = stride;
+    a.num_frames = nframes;
+    a.bounces = p->ray_bounces;
+    a.tiles_x = (p->width + 7) / 8;
+    a.tile_y0 = bl.tile_y0;
+    a.stripe_period = bl.stripe_period;
+    a.strip_tiles = PT_STRIP_W * bl.tile_rows;
+    a.tiles_per_frame = ((a.tiles_x + PT_STRIP_W - 1) / PT_STRIP_W) * a.strip_tiles;
+    a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
+    a.pixels = (uint32_t)((size_t)p->width * p->height);
+    a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
+    a.min_trav = c->tune_min_trav;
+    a.min_service = c->tune_min_service;
+    a.w_inner = c->tune_w_inner;
+    a.w_leaf = c->tune_w_leaf;
+    if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
+    a.samples = nullptr;
+    a.spill = nullptr;
+    a.spill_stride = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
+    a.counters = (p->flags & RT_FLAG_COUNTERS) ? c->d_counters : nullptr;
+}
+
+static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, hipStream_t st) {
+    dim3 grid(c->num_cus * PT_BLOCKS_PER_CU), blk(PT_BLOCK);
+#define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, st, c->sc, dc, a)
+    if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
+    else { if (fix) PATHS(false, true); else PATHS(false, false); }
+#undef PATHS
+}
+
+static void launch_k_accumulate(const rt_context* c, const rt_params* p, const BandLayout& bl, const PathsArgs& a, const float4* prev,
+                                float4* out) {
+    const bool sum = (p->flags & RT_FLAG_SUM) != 0;
+    const uint32_t read_prev = (sum || a.frame_base != 0) ? 1u : 0u;
+    if (bl.px.num_pixels)
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((bl.px.num_pixels + 255) / 256)), dim3(256), 0, c->stream,
+                           (const float4*)a.samples, a.num_frames, a.pixels, bl.px, a.frame_base, a.frame_stride, sum ? 1u : 0u,
+                           read_prev, prev, out);
 }
 
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
@@ -369,7 +417,6 @@ static BandLayout band_layout(const rt_params* p) {
 // frame-to-frame dependency, goes to the context's stream.
 static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
                               uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined) {
-    const bool sum = (p->flags & RT_FLAG_SUM) != 0;
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     size_t pixels = (size_t)p->width * p->height;
@@ -379,32 +426,13 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (count || c->profiling) pipelined = false;
     const uint32_t slot = pipelined ? (c->lane_next++ % RT_LANES) : 0u;
     hipStream_t pst = pipelined ? c->lane_stream[slot] : c->stream;
-    const size_t spill_threads = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
-    PathsArgs a;
-    a.frame_base = frame_base;
-    a.frame_stride = stride;
-    a.num_frames = nframes;
-    a.bounces = p->ray_bounces;
     const BandLayout bl = band_layout(p);
-    a.tiles_x = (p->width + 7) / 8;
-    a.tile_y0 = bl.tile_y0;
-    a.stripe_period = bl.stripe_period;
-    a.strip_tiles = PT_STRIP_W * bl.tile_rows;
-    a.tiles_per_frame = ((a.tiles_x + PT_STRIP_W - 1) / PT_STRIP_W) * a.strip_tiles;
-    a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
-    a.pixels = (uint32_t)pixels;
-    a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
-    a.min_trav = c->tune_min_trav;
-    a.min_service = c->tune_min_service;
-    a.w_inner = c->tune_w_inner;
-    a.w_leaf = c->tune_w_leaf;
-    if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
-    // every internal stream has its own slot of the staging area (paths_batch frames) and its own spill copy
-    a.samples = c->d_samples + (size_t)slot * paths_batch(pixels) * pixels;
-    a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * spill_threads : nullptr;
-    a.spill_stride = spill_threads;
-    a.counters = count ? c->d_counters : nullptr;
-    dim3 grid(c->num_cus * PT_BLOCKS_PER_CU), blk(PT_BLOCK);
+    PathsArgs a;
+    fill_paths_args(c, p, bl, frame_base, stride, nframes, a);
+    // every internal stream owns a fixed share of the staging area and its own spill copy, whatever the image size of
+    // the launch: launches of different sizes that are in flight together never touch each other's samples
+    a.samples = c->d_samples + (size_t)slot * (c->samples_bytes / RT_LANES / sizeof(float4));
+    a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * a.spill_stride : nullptr;
     if (pipelined) {
         // the slot's previous reader (an accumulate on the context's stream) must have finished
         HIPCHK(c, hipStreamWaitEvent(pst, c->slot_free[slot], 0));
@@ -414,10 +442,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     }
     {
         LaunchTimer lt(c, RT_K_PATHS);
-#define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, pst, c->sc, dc, a)
-        if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
-        else { if (fix) PATHS(false, true); else PATHS(false, false); }
-#undef PATHS
+        launch_k_paths(c, dc, a, count, fix, pst);
     }
     HIPCHK(c, hipGetLastError());
     if (pipelined) {
@@ -426,11 +451,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     }
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
-        uint32_t read_prev = (sum || frame_base != 0) ? 1u : 0u;
-        if (bl.px.num_pixels)
-            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((bl.px.num_pixels + 255) / 256)), dim3(256), 0, c->stream,
-                               (const float4*)a.samples, nframes, (uint32_t)pixels, bl.px, frame_base, stride,
-                               sum ? 1u : 0u, read_prev, prev, out);
+        launch_k_accumulate(c, p, bl, a, prev, out);
     }
     HIPCHK(c, hipGetLastError());
     // the staging slots this call used are free again once its accumulate has run

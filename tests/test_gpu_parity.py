@@ -219,6 +219,35 @@ def test_single_frame_calls_pipeline_and_mix_with_batches(pkg, oracle, gpu_ctx, 
         b.free()
 
 
+def test_pipelined_frames_of_two_image_sizes_do_not_share_staging(pkg, oracle, gpu_ctx, scenes):
+    """Frame-by-frame calls of two image sizes interleaved on one context without any host synchronisation: the path
+    kernels of up to two calls are in flight together, each in its own fixed share of the staging area, so a large
+    frame launched while a small one still waits for its accumulate step must not overwrite the small one's samples."""
+    scene = scenes("dragon80k")
+    cam = pkg.make_camera(**CAMERAS["dragon80k"])
+    gpu_ctx.upload_scene(scene)
+    big, small = (1920, 1080), (64, 64)
+    pb, ps = pkg.make_params(*big), pkg.make_params(*small)
+    gpu_ctx.render_device(cam, pkg.make_params(*big, frames=16), pkg.DeviceBuffer(big[0] * big[1] * 16).ptr)  # sizes the staging area
+    gpu_ctx.synchronize()
+    B = [pkg.DeviceBuffer(big[0] * big[1] * 16) for _ in range(2)]
+    S = [pkg.DeviceBuffer(small[0] * small[1] * 16) for _ in range(2)]
+    n = 6
+    for f in range(n):       # big f, small f, big f+1, ... : consecutive launches alternate between the two slots
+        gpu_ctx.raytrace_frame(cam, pb, f, B[(f + 1) & 1].ptr, B[f & 1].ptr)
+        gpu_ctx.raytrace_frame(cam, ps, f, S[(f + 1) & 1].ptr, S[f & 1].ptr)
+        gpu_ctx.raytrace_frame(cam, ps, f, S[(f + 1) & 1].ptr, S[f & 1].ptr)   # same frame again: shifts the slot parity
+    gpu_ctx.synchronize()
+    got_b = B[(n - 1) & 1].to_array((big[1], big[0], 4), np.float32)
+    got_s = S[(n - 1) & 1].to_array((small[1], small[0], 4), np.float32)
+    want_s, _ = oracle.render(scene, cam, pkg.make_params(*small, frames=n))
+    assert np.array_equal(bits(got_s), bits(want_s))
+    want_b = gpu_ctx.render(cam, pkg.make_params(*big, frames=n))
+    assert np.array_equal(bits(got_b), bits(want_b))
+    for b in B + S:
+        b.free()
+
+
 def test_sample_partition_sum_matches_running_mean(pkg, gpu_ctx, scenes):
     """The multi-GPU decomposition on one GPU: G interleaved frame subsets summed, divided by the frame
     count, against the sequential running mean -- equal to fp32 rounding, far inside 1e-3."""
