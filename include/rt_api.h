@@ -23,6 +23,7 @@
 #ifndef RT_API_H
 #define RT_API_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -176,6 +177,21 @@ int rt_get_built_links(rt_context* ctx, int32_t* links);
  * caller can observe -- work enqueued on that stream after the call sees the finished frame. */
 int rt_raytrace_frame(rt_context* ctx, const rt_camera* cam, const rt_params* params,
                       uint32_t frame_count, const float* d_prev_frame, float* d_out_frame);
+
+/* rt_raytrace_frame for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and
+ * bit-identical pixels, but it calls no hipMalloc / hipFree: the staged samples of the frame and the traversal-stack
+ * spill area live in a static device array of RT_NOALLOC_SCRATCH_BYTES (128 MiB) that every GPU the library runs
+ * on holds until the process ends.  Limits: default pipeline only (render mode 1, rays_per_pixel 1, ray_bounces >= 1,
+ * no RT_FLAG_MEGAKERNEL / RT_FLAG_WAVEFRONT), and
+ *     width*height*16 + (depth > 8 ? depth - 7 : 0) * 8 * (2048 * compute units)  <=  RT_NOALLOC_SCRATCH_BYTES
+ * with depth = the deepest level of the BVH, root = 0 (on an MI355X, 256 compute units, 1920x1080 fits with trees up
+ * to depth 31, 1280x720 up to depth 35); larger requests fail with RT_ELIMIT.  Both kernels
+ * run on the context's stream, so calls on one context are ordered; all contexts of one GPU share that GPU's array,
+ * so calls of DIFFERENT contexts (or processes' threads) that overlap on one GPU race -- serialise them. */
+#define RT_NOALLOC_SCRATCH_BYTES ((size_t)128 << 20)
+int rt_raytrace_frame_noalloc(rt_context* ctx, const rt_camera* cam, const rt_params* params,
+                              uint32_t frame_count, const float* d_prev_frame, float* d_out_frame);
 
 /* render(scene, camera, spp) -> framebuffer: params->frames consecutive dispatches starting
  * at frame_base, accumulated in place in d_accum (DEVICE pointer, W*H*4 floats).  With

@@ -122,6 +122,7 @@ HIP_SYMBOLS = [
     "rt_get_built_scene",
     "rt_get_built_links",
     "rt_raytrace_frame",
+    "rt_raytrace_frame_noalloc",
     "rt_render_device",
     "rt_render",
     "rt_primary_hits",
@@ -189,6 +190,7 @@ def load_hip() -> C.CDLL:
         lib.rt_get_built_scene.argtypes = [vp, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                            c_int32_p, c_float_p]
         lib.rt_raytrace_frame.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, vp, vp]
+        lib.rt_raytrace_frame_noalloc.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), C.c_uint32, vp, vp]
         lib.rt_render_device.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), vp]
         lib.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), c_float_p]
         lib.rt_primary_hits.argtypes = [vp, C.POINTER(RtCamera), C.c_int32, C.c_int32, c_int32_p, c_float_p]
@@ -458,6 +460,14 @@ class RenderContext:
                 self.ctx, C.byref(cam), C.byref(params), frame_count, C.c_void_p(d_prev_ptr), C.c_void_p(d_out_ptr)
             ),
             "rt_raytrace_frame",
+        )
+
+    def raytrace_frame_noalloc(self, cam, params, frame_count: int, d_prev_ptr: int, d_out_ptr: int):
+        self._check(
+            self.lib.rt_raytrace_frame_noalloc(
+                self.ctx, C.byref(cam), C.byref(params), frame_count, C.c_void_p(d_prev_ptr), C.c_void_p(d_out_ptr)
+            ),
+            "rt_raytrace_frame_noalloc",
         )
 
     def primary_hits(self, cam: RtCamera, width: int, height: int):

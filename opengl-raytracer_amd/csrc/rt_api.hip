@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -32,9 +33,39 @@
 #define RT_LANES 2            // internal streams that single-frame calls rotate over (2, 4 and 6 measure the same, 3 is slower)
 #endif
 
+// Scratch of rt_raytrace_frame_noalloc: staged samples of one frame followed by the stack spill area.  Every GPU the
+// library runs on holds its own copy of the array, at its own address, until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: scratch_for_device() resolves it once per device and every
+// use below goes through the resolved pointer.
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[RT_MAX_DEVICES] = {};
+
+// Device address of this device's copy of `scratch` (device must be current).  nullptr and *err set on failure.
+static void* scratch_for_device(int device, hipError_t* err) {
+    *err = hipSuccess;
+    if (device < 0 || device >= RT_MAX_DEVICES) {
+        *err = hipErrorInvalidDevice;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            *err = e != hipSuccess ? e : hipErrorInvalidSymbol;
+            return nullptr;
+        }
+        g_scratch_ptr[device] = ptr;
+    }
+    return g_scratch_ptr[device];
+}
+
 struct EventPair {
     hipEvent_t a, b;
     int cls;
@@ -115,6 +146,7 @@ struct rt_context {
     int tune_cache = -1;  // >= 0: stage at most this many records in LDS
 
     unsigned long long* d_counters = nullptr;
+    unsigned char* scratch_ptr = nullptr;  // this device's copy of the static scratch array (rt_raytrace_frame_noalloc)
 
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -489,6 +521,13 @@ int rt_create(int device_id, rt_context** out_ctx) {
         return rc;
     }
     c->stream = c->own_stream;
+    // this device's copy of the static scratch array, resolved once per device while that device is current
+    c->scratch_ptr = (unsigned char*)scratch_for_device(device_id, &e);
+    if (!c->scratch_ptr) {
+        int rc = fail(nullptr, RT_EDEVICE, "hipGetSymbolAddress(scratch) failed on device %d: %s", device_id, hipGetErrorString(e));
+        rt_destroy(c);
+        return rc;
+    }
     for (int k = 0; k < RT_LANES; k++) {
         if ((e = hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming)) != hipSuccess ||
@@ -1138,6 +1177,45 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
         else { if (fix) TAIL(false, true); else TAIL(false, false); }
 #undef TAIL
     }
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+// rt_raytrace_frame for callers that cannot allocate: same kernels, staging and spill area in the static scratch array.
+int rt_raytrace_frame_noalloc(rt_context* c, const rt_camera* cam, const rt_params* p, uint32_t frame_count,
+                              const float* d_prev_frame, float* d_out_frame) {
+    int rc = check_render_args(c, cam, p);
+    if (rc != RT_OK) return rc;
+    if (!d_out_frame) return fail(c, RT_EINVAL, "d_out_frame is NULL");
+    if ((p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) || p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 ||
+        p->ray_bounces == 0)
+        return fail(c, RT_EINVAL, "rt_raytrace_frame_noalloc supports the default pipeline only (render mode 1, rays_per_pixel 1, ray_bounces >= 1)");
+    const bool sum = (p->flags & RT_FLAG_SUM) != 0;
+    if (!d_prev_frame && (sum || frame_count != 0)) return fail(c, RT_EINVAL, "d_prev_frame is NULL for frame %u", frame_count);
+    // scratch layout: [staged samples of one frame: pixels x 16 B][pad to 256 B][spill: entries x threads x 8 B]
+    const size_t pixels = (size_t)p->width * p->height;
+    const size_t spill_threads = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
+    const size_t spill_entries = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
+    const size_t samples_bytes = (pixels * sizeof(float4) + 255) & ~(size_t)255;
+    const size_t need = samples_bytes + spill_entries * spill_threads * sizeof(uint2);
+    if (need > RT_NOALLOC_SCRATCH_BYTES)
+        return fail(c, RT_ELIMIT,
+                    "rt_raytrace_frame_noalloc: %dx%d pixels with a BVH of depth %d need %zu bytes of scratch (16 per pixel + %zu per "
+                    "level beyond %d), the static scratch holds %zu; use rt_raytrace_frame",
+                    p->width, p->height, c->max_depth, need, spill_threads * sizeof(uint2), PT_STACK - 1, (size_t)RT_NOALLOC_SCRATCH_BYTES);
+    HIPCHK(c, hipSetDevice(c->device));
+    const DCamera dc = make_dcamera(cam, p->width, p->height);
+    const BandLayout bl = band_layout(p, false);
+    PathsArgs a;
+    fill_paths_args(c, p, bl, frame_count, 1u, 1u, a);
+    a.samples = (float4*)c->scratch_ptr;
+    a.spill = spill_entries ? (uint2*)(c->scratch_ptr + samples_bytes) : nullptr;
+    // Both kernels go to the context's stream, so consecutive calls on one context run one after the other.  Nothing in
+    // the scratch has to start at zero: the path kernel writes the sample of every pixel of the band and every spill
+    // entry before anything reads it.
+    launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, (p->flags & RT_FLAG_FIX_INVDIR) != 0, c->stream);
+    HIPCHK(c, hipGetLastError());
+    launch_k_accumulate(c, p, bl, a, (const float4*)d_prev_frame, (float4*)d_out_frame);
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
