@@ -7,16 +7,22 @@
 A step is one frame (one dispatch of the reference: one sample per pixel over the whole image) per
 GPU.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the frames are partitioned by
 sample index -- rank g renders frameCount g, g+N, ... of the same scene and camera into a private
-fp32 SUM buffer -- and one RCCL reduce of the accumulators to rank 0 closes the timed region; that is
-weak scaling (fixed work per GPU).  Rays are counted on the device (calls of the closest-hit routine,
-raytrace.glsl:245) in a separate untimed pass over exactly the timed frames.
+fp32 SUM buffer -- and RCCL reduces of the accumulators to rank 0 close the timed region; that is
+weak scaling (fixed work per GPU).  The timed region (exactly K steps between barrier + synchronize)
+is repeated --reps times and the line reports the median repetition.  Rays are counted on the device
+(calls of the closest-hit routine, raytrace.glsl:245) in a separate untimed pass over exactly the
+timed frames.
 
 Besides the contract's fields the JSON line carries
-  roofline      algorithmic bytes of the dominant kernel / its mean launch duration (HIP events on
-                the launch stream, separate profiled pass in which launches run one at a time; in
-                the timed region the library overlaps consecutive launches) against the 8 TB/s HBM peak
+  roofline      the dominant kernel against the ceiling that binds it, vector-instruction issue:
+                algorithmic lane-operations per launch / its mean launch duration (HIP events on the
+                launch stream, separate pass in which launches run one at a time) against the chip's
+                fp32 lane-operations per second.  traffic, hbm and l2 come from rocprofv3 PMC passes
+                of the same build (profiles/pmc_traffic.json; null when that file is of another build)
+  timing        median / min / max of the repetitions
+  reduce        (under torch.distributed) the exposed time of the closing reduces
   cpu_baseline  the CPU oracle (a port of the reference's GLSL path) timed on this host's cores on a
-                bounded sample of the same workload
+                bounded sample of the same workload, all cores and one core
 """
 from __future__ import annotations
 
@@ -33,10 +39,13 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth of the 8 XCDs
 VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T fp32 lane-ops/s (157.3 TFLOP/s with FMAs; an FMA counts once here)
 WORKLOADS = {
     # name: (obj, camera position, width, height)
     "dragon80k_1080p": ("dragon80k.obj", (0.0, 0.0, -5.5), 1920, 1080),
+    # the same workload driven like the reference's loop: one call of the boundary per frame, two buffers
+    "dragon80k_1080p_frame_loop": ("dragon80k.obj", (0.0, 0.0, -5.5), 1920, 1080),
     "teapot_1080p": ("teapot.obj", (0.0, 0.0, -2.0), 1920, 1080),
     "dragon80k_4k": ("dragon80k.obj", (0.0, 0.0, -5.5), 3840, 2160),
     # ~10M-triangle stress scene: baked grid of dragon stand-ins and teapots (generated in memory, ~15 s)
@@ -63,22 +72,48 @@ def algorithmic_lane_ops(c) -> float:
     return 27.0 * box + 60.0 * tri + 150.0 * rays
 
 
+def load_pmc(workload: str, kernel: str, build: str, fix_invdir: bool):
+    """PMC figures per frame of `kernel` from profiles/pmc_traffic.json -- only if they were taken with THIS build of
+    the library on THIS workload (the file carries the build id of the library that was profiled)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json missing"
+    if tj.get("_build") != build:
+        return None, f"profiles/pmc_traffic.json is of build {tj.get('_build')}, the library is {build}"
+    if tj.get("_workload") != workload or fix_invdir:
+        return None, f"profiles/pmc_traffic.json is of workload {tj.get('_workload')}"
+    k = tj.get(kernel)
+    if not k or k.get("hbm_bytes_per_frame") is None:
+        return None, f"profiles/pmc_traffic.json has no entry for {kernel}"
+    return dict(k, _source=tj.get("_source"), _frames_per_launch=tj.get("_frames_per_launch")), None
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=7,
+                    help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is repeated this many "
+                         "times; the line reports the median repetition, min and max next to it")
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true", help="non-default: refresh invDir after bounces")
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"],
                     help="N > 1: 'samples' = each GPU renders its own frames (weak scaling, the default); 'tiles' = every "
                          "GPU renders its horizontal band of every frame (strong scaling)")
+    ap.add_argument("--reduce-bands", type=int, default=2,
+                    help="sample partition under torch.distributed: the image is finished in this many row bands, the reduce "
+                         "of one band travelling while the next renders (1 = one reduce of the whole image at the end)")
     ap.add_argument("--dynamic-update", default="rebuild", choices=["rebuild", "refit"],
                     help="grid9m_dynamic: rebuild the BVH every step (default) or refit the first build's tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
+    args.reps = max(1, args.reps)
 
     import torch
 
@@ -100,12 +135,18 @@ def main() -> int:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
+    # One real (non-default) stream carries everything: the library's accumulate kernels, torch's fills and scales, and
+    # the point the collectives are ordered against.  (rt_set_stream(NULL) means "the context's own stream", so torch's
+    # default stream, whose handle is 0, cannot be shared with the library.)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
 
     pkg = entry.load_package()
     from opengl_raytracer_amd import partition
     obj, cam_pos, W, H = WORKLOADS[args.workload]
     if args.workload == "grid9m_dynamic":
         return run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank, cam_pos, W, H)
+    frame_loop = args.workload.endswith("_frame_loop")
     if obj is None:
         sys.path.insert(0, os.path.join(ROOT, "opengl-raytracer_amd", "tools"))
         import gen_scenes
@@ -119,72 +160,114 @@ def main() -> int:
     cam = pkg.make_camera(pos=cam_pos)
     ctx = pkg.RenderContext(local_rank)
     ctx.upload_scene(scene)
-    stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
+    build_id = pkg.build_id()
 
-    # N = 1 accumulates with the reference's running mean; N > 1 needs plain sums for the reduce
+    # without torch.distributed the frames accumulate with the reference's running mean; under it (also with a single
+    # rank) every rank renders plain sums that one reduce to rank 0 adds up
     tiles = args.partition == "tiles" and world > 1
-    base_flags = pkg.RT_FLAG_SUM if (world > 1 and not tiles) else 0
+    sum_mode = dist is not None and not tiles
+    mode = "tiles" if tiles else "samples"
+    reduce_bands = args.reduce_bands if (sum_mode and not frame_loop) else 1
+    base_flags = pkg.RT_FLAG_SUM if sum_mode else 0
     if args.fix_invdir:
         base_flags |= pkg.RT_FLAG_FIX_INVDIR
     if args.pipeline == "megakernel":
         base_flags |= pkg.RT_FLAG_MEGAKERNEL
+        reduce_bands = 1   # bands are a feature of the default pipeline
     if args.pipeline == "wavefront":
         base_flags |= pkg.RT_FLAG_WAVEFRONT
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        reduce_bands = 1
+    # frame_loop drives rt_raytrace_frame with two buffers, as the reference's loop does with its two textures
+    bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if frame_loop else 1)]
+    scratch = [torch.zeros_like(b) for b in bufs]
+    last = {"buf": bufs[0]}
 
-    def render_steps(first_step: int, nsteps: int, flags: int, target, bounces: int = 100):
-        """nsteps steps of this rank (frameCount (first_step+k)*world + rank) in ONE call of the boundary:
-        the library is free to render the frames of a call concurrently."""
-        if tiles:  # every rank renders the same frames, restricted to its band; bands are disjoint, so the
-            # closing sum-reduce of the (elsewhere zero) buffers is the gather
-            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=first_step, frames=nsteps, flags=flags, band=(rank, world),
-                                interleaved=True)
-        else:
-            base, stride, n = partition.rank_frames(rank, world, first_step, nsteps)
-            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=base, frames=n, frame_stride=stride, flags=flags)
-        ctx.render_device(cam, p, target.data_ptr())
+    def make_render(target, flags, bounces=100):
+        def render(frame_base, stride, frames, band, rows):
+            if frame_loop:  # one call of the boundary per frame (main.cpp:193), ping-pong (main.cpp:189-191,199)
+                p = pkg.make_params(W, H, ray_bounces=bounces, flags=flags)
+                for k in range(frames):
+                    ctx.raytrace_frame(cam, p, frame_base + k * stride, target[(k + 1) & 1].data_ptr(), target[k & 1].data_ptr())
+                last["buf"] = target[(frames - 1) & 1]
+                return
+            # all frames of the rank in ONE call: the library is free to render the frames of a call concurrently
+            p = pkg.make_params(W, H, ray_bounces=bounces, frame_base=frame_base, frames=frames, frame_stride=stride, flags=flags,
+                                band=band, interleaved=tiles)
+            ctx.render_device(cam, p, target[0].data_ptr())
+            last["buf"] = target[0]
+        return render
+
+    marks = []
+
+    def start_reduce(rows):
+        if dist is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)   # the rows' last accumulate has been enqueued: what follows until `done` is exposed reduce time
+        marks.append(ev)
+        return dist.reduce(last["buf"][rows[0]:rows[1]], dst=0, async_op=True)
+
+    def finish(work):
+        if work is not None:
+            work.wait()     # orders the stream behind the collective; does not block the host
+
+    def no_reduce(rows):
+        return None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- warm-up (untimed) ------------------------------------------------------------------------
-    if args.warmup:
-        render_steps(0, args.warmup, base_flags, accum)
-    if dist is not None:
-        warm = accum.clone()
-        dist.reduce(warm, dst=0)
-        del warm
-    accum.zero_()
+    def one_pass(target, flags, reduce=True, bounces=100):
+        partition.render_partitioned(rank=rank, world=world, steps=args.steps, height=H, render=make_render(target, flags, bounces),
+                                     start_reduce=start_reduce if reduce else no_reduce, finish=finish, mode=mode,
+                                     reduce_bands=reduce_bands)
 
-    # ---- timed region: exactly K steps + the closing reduce -----------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    render_steps(0, args.steps, base_flags, accum)
-    if dist is not None:
-        dist.reduce(accum, dst=0)
-    if rank == 0 and world > 1 and not tiles:
-        accum.mul_(1.0 / float(args.steps * world))  # sum -> mean image
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    image_mean = accum[..., :3].mean(dim=(0, 1)).tolist() if rank == 0 else None
+    # ---- warm-up (untimed): W steps, and one pass through the collective --------------------------------
+    if args.warmup:
+        saved = args.steps
+        args.steps = args.warmup
+        one_pass(bufs, base_flags)
+        args.steps = saved
+    elif dist is not None:
+        finish(start_reduce((0, H)))
+    marks.clear()
+
+    # ---- timed region: exactly K steps + the closing reduce, repeated --reps times -----------------------
+    times, reduce_ms = [], []
+    for _ in range(args.reps):
+        barrier()
+        t0 = time.perf_counter()
+        if sum_mode:
+            for b in bufs:
+                b.zero_()
+        one_pass(bufs, base_flags)
+        done = torch.cuda.Event(enable_timing=True)
+        done.record(stream)
+        if rank == 0 and sum_mode:
+            last["buf"].mul_(1.0 / float(args.steps * world))  # sum -> mean image
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            reduce_ms.append(float(marks[-1].elapsed_time(done)))
+            marks.clear()
+        times.append(elapsed)
+    order = sorted(times)
+    elapsed = order[len(order) // 2] if len(order) % 2 else 0.5 * (order[len(order) // 2 - 1] + order[len(order) // 2])
+    image_mean = last["buf"][..., :3].mean(dim=(0, 1)).tolist() if rank == 0 else None
 
     # ---- untimed: count the rays of exactly those frames ---------------------------------------------
-    scratch = torch.zeros_like(accum)
-
     def count_pass(flags, bounces=100):
         ctx.reset_counters()
-        render_steps(0, args.steps, flags | pkg.RT_FLAG_COUNTERS, scratch, bounces)
+        one_pass(scratch, flags | pkg.RT_FLAG_COUNTERS, reduce=False, bounces=bounces)
         return ctx.counters().astype(np.float64)
 
     counters = count_pass(base_flags)
-    rays_local = counters[2]
     if dist is not None:
         tot = torch.tensor(counters, dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
@@ -195,8 +278,9 @@ def main() -> int:
     frames_total = args.steps if tiles else args.steps * world
 
     # ---- untimed: per-kernel durations with HIP events on the launch stream ------------------------
+    # (profiled launches run one at a time on the context's stream; in the timed region consecutive launches overlap)
     ctx.set_profiling(True)
-    render_steps(0, args.steps, base_flags, scratch)
+    one_pass(scratch, base_flags, reduce=False)
     ms, launches = ctx.kernel_times()
     ctx.set_profiling(False)
     names = pkg.KERNEL_CLASS_NAMES
@@ -209,27 +293,30 @@ def main() -> int:
         dom_counters[3] = 0.0  # so do the normal/colour fetches
     else:
         dom_counters = counters.copy()
-    dom_bytes_per_launch = algorithmic_bytes(dom_counters) / max(1, int(launches[dominant]))
-    dom_ms = float(ms[dominant]) / max(1, int(launches[dominant]))
-    achieved_gbs = dom_bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    n_launch = max(1, int(launches[dominant]))
+    dom_ms = float(ms[dominant]) / n_launch
+    dom_s = dom_ms * 1e-3 if dom_ms > 0 else float("inf")
+    dom_bytes_per_launch = algorithmic_bytes(dom_counters) / n_launch
+    dom_ops_per_launch = algorithmic_lane_ops(dom_counters) / n_launch
+    frames_per_launch = args.steps / n_launch  # whole-image frames (a launch over a band counts by its share of the rows)
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            # PMC bytes per frame of the profiled workload, scaled to this run's launches of the dominant kernel
-            with open(tpath) as f:
-                tj = json.load(f)
-            per_frame = tj.get(names[dominant], {}).get("hbm_bytes_per_frame")
-            if per_frame is not None and tj.get("_workload") == args.workload and not args.fix_invdir:
-                traffic = round(per_frame * args.steps / max(1, int(launches[dominant])))
-        except Exception:
-            traffic = None
+    pmc, pmc_why = load_pmc(args.workload, names[dominant], build_id, args.fix_invdir)
+    traffic = hbm = l2 = None
+    if pmc is not None:
+        traffic = round(pmc["hbm_bytes_per_frame"] * frames_per_launch)
+        hbm = {"achieved": round(traffic / dom_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(traffic / dom_s / 1e9 / HBM_PEAK_GBS, 4)}
+        if pmc.get("l2_bytes_per_frame") is not None:
+            l2b = pmc["l2_bytes_per_frame"] * frames_per_launch
+            l2 = {"achieved": round(l2b / dom_s / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(l2b / dom_s / 1e9 / L2_PEAK_GBS, 4), "bytes_per_launch": round(l2b),
+                  "hit_rate": pmc.get("l2_hit_rate")}
 
     if rank == 0:
         value = total_rays / elapsed / 1e6
+        tlane = dom_ops_per_launch / dom_s / 1e12
         out = {
-            "metric": "Mrays/s, 80K-tri dragon stand-in 1080p 1spp" if args.workload == "dragon80k_1080p"
+            "metric": "Mrays/s, 80K-tri dragon stand-in 1080p 1spp" if args.workload.startswith("dragon80k_1080p")
             else f"Mrays/s, {args.workload}",
             "value": round(value, 2),
             "unit": "Mrays/s",
@@ -246,11 +333,21 @@ def main() -> int:
             "config": {
                 "workload": f"{args.workload}: {obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
                             f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
-                            f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}",
+                            f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}"
+                            + (", one call of the boundary per frame with ping-pong buffers (the reference's loop, main.cpp:183-203)"
+                               if frame_loop else ""),
                 "pipeline": args.pipeline,
                 "frames_total": frames_total,
                 "parallelism": (f"tile-partition x{world}" if tiles else f"sample-partition x{world}") if world > 1 else "single GPU",
             },
+            "timing": {
+                "repetitions": args.reps,
+                "region_ms": {"median": round(elapsed * 1e3, 4), "min": round(order[0] * 1e3, 4), "max": round(order[-1] * 1e3, 4)},
+                "value_best": round(total_rays / order[0] / 1e6, 2),
+                "note": "every repetition times exactly `steps` steps between barrier + synchronize; value and ms_per_step are "
+                        "the median repetition's",
+            },
+            "build": build_id,
             "rays_per_frame": round(total_rays / frames_total, 1),
             "work_per_ray": {
                 "box_tests": round(counters_all[0] / total_rays, 3),
@@ -259,32 +356,44 @@ def main() -> int:
                 "hit_fraction": round(counters_all[3] / total_rays, 4),
                 "rays_per_path": round(total_rays / counters_all[5], 4),
                 "algorithmic_bytes": round(algorithmic_bytes(counters_all) / total_rays, 1),
+                "algorithmic_lane_ops": round(algorithmic_lane_ops(counters_all) / total_rays, 1),
             },
             "kernels_ms_per_frame": {names[k]: round(float(ms[k]) / args.steps, 4) for k in range(len(names)) if launches[k]},
             "image_mean_rgb": [round(x, 5) for x in image_mean],
+            # The ceiling that binds this kernel is vector-instruction issue (the scene is cache-resident, HBM and L2
+            # are far from their peaks, there is no matrix work): frac is the share of the chip's fp32 lane-operations
+            # per second that went into the algorithm's own arithmetic.
             "roofline": {
-                "bound": "hbm",
+                "bound": "valu",
                 "kernel": names[dominant],
-                "achieved": round(achieved_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "achieved": round(tlane, 3),
+                "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2),
+                "unit": "Tlane-op/s",
+                "frac": round(tlane * 1e12 / VALU_PEAK_LANE_OPS, 4),
                 "traffic": traffic,
                 "launch_ms": round(dom_ms, 4),
-                "algorithmic_bytes_per_launch": round(dom_bytes_per_launch, 0),
-                "note": "scene is L2/Infinity-Cache resident, so algorithmic bytes/s may exceed the HBM peak; "
-                        "the binding ceiling is VALU issue (see alu)",
-                "alu": {
-                    "achieved_lane_ops_per_s": round(algorithmic_lane_ops(counters_all) / elapsed, 0),
-                    "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                    "frac": round(algorithmic_lane_ops(counters_all) / elapsed / VALU_PEAK_LANE_OPS / world, 4),
-                },
+                "launches": n_launch,
+                "frames_per_launch": round(frames_per_launch, 3),
+                "lane_ops_per_launch": round(dom_ops_per_launch, 0),
+                "frac_end_to_end": round(algorithmic_lane_ops(counters_all) / elapsed / VALU_PEAK_LANE_OPS / world, 4),
+                "hbm": hbm,
+                "l2": l2,
+                "algorithmic_bytes": {"per_launch": round(dom_bytes_per_launch, 0), "gb_per_s": round(dom_bytes_per_launch / dom_s / 1e9, 1),
+                                      "note": "bytes the reference's access pattern would move; served by L1/L2/LDS here, not a "
+                                              "fraction of any peak"},
+                "note": ("traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per frame of 16-frame launches of this build ("
+                         + str(pmc.get("_source")) + ") x frames per launch of this run") if pmc is not None
+                        else f"traffic: null -- {pmc_why}",
             },
         }
+        if dist is not None:
+            rs = sorted(reduce_ms)
+            out["reduce"] = {"bands": reduce_bands, "exposed_ms_median": round(rs[len(rs) // 2], 4),
+                             "share_of_region": round(rs[len(rs) // 2] / (elapsed * 1e3), 4),
+                             "note": "time from the last band's final accumulate to the completion of all reduces (rank 0)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, cam, W, H, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    _ = rays_local
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -400,10 +509,12 @@ def run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank,
 
 
 def cpu_baseline(pkg, scene, cam, W, H, budget_s):
-    """The oracle on this host's cores, on whole frames of the same workload until about budget_s
-    seconds of wall time are spent (at least one frame)."""
+    """The oracle on this host: two thirds of budget_s on whole frames with all the cores this process may use, one
+    third on one core (stripes of 8 rows spread over frame 0)."""
     oracle = entry.load_oracle()
-    threads = min(oracle.max_threads(), 16)
+    # OpenMP's default team: OMP_NUM_THREADS when the host sets it (a GPU box gives a job a share of its cores), else
+    # every core the process may run on
+    threads = oracle.max_threads()
     nrm = oracle.normals(scene)
     img = np.zeros((H, W, 4), dtype=np.float32)
     p = pkg.make_params(W, H, frames=1)
@@ -415,7 +526,17 @@ def cpu_baseline(pkg, scene, cam, W, H, budget_s):
         rays += float(c[2])
         frames += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or frames >= 64:
+        if dt >= budget_s * 2.0 / 3.0 or frames >= 64:
+            break
+    # one core: 8-row stripes of frame 0 in an order that covers the image evenly at every stopping point
+    stripes = [r for off in (0, 32, 16, 48, 8, 40, 24, 56) for r in range(off, H, 64)]
+    rays1, rows1 = 0.0, 0
+    t1 = time.perf_counter()
+    for r in stripes:
+        rays1 += float(oracle.frame_rows(scene, nrm, cam, p, 0, img, r, min(r + 8, H), 1)[2])
+        rows1 += min(r + 8, H) - r
+        dt1 = time.perf_counter() - t1
+        if dt1 >= budget_s / 3.0:
             break
     return {
         "value": round(rays / dt / 1e6, 3),
@@ -423,8 +544,11 @@ def cpu_baseline(pkg, scene, cam, W, H, budget_s):
         "cores": threads,
         "kind": "port",
         "sample": f"{frames} full {W}x{H} frames (frameCount 0..{frames - 1}) of the same scene and camera, "
-                  f"{dt:.1f} s wall, OpenMP over image rows",
+                  f"{dt:.1f} s wall, OpenMP over image rows, {threads} threads (the OpenMP default team of this process; "
+                  f"the host shows {os.cpu_count()} CPUs)",
         "fps": round(frames / dt, 3),
+        "one_core": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                     "sample": f"{rows1} of {H} rows of frame 0 in 8-row stripes spread over the image, {dt1:.1f} s wall"},
     }
 
 

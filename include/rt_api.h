@@ -237,7 +237,7 @@ int rt_kernel_times(rt_context* ctx, float out_ms[RT_NUM_KERNEL_CLASSES],
  * out[4n..5n) = 1/x, out[5n..6n) = pow(x, 0.35).  Lets tests compare device and host bit for bit. */
 int rt_selftest_math(rt_context* ctx, const float* x, int32_t n, float* out);
 
-/* Library build identification, e.g. "rt_hip gfx950 <date>". */
+/* Library build identification: "rt_hip gfx950 <hash of the sources it was built from> <date>". */
 const char* rt_version(void);
 
 #ifdef __cplusplus

@@ -209,6 +209,12 @@ def load_hip() -> C.CDLL:
     return _hip
 
 
+def build_id() -> str:
+    """The source hash librt_hip.so was built from (second-to-last field group of rt_version())."""
+    parts = load_hip().rt_version().decode().split()
+    return parts[2] if len(parts) >= 3 else "unknown"
+
+
 class DeviceBuffer:
     """Plain device memory from the HIP runtime the render library is linked against, for callers that hold no other
     GPU library (the tests).  Allocated on the current HIP device."""

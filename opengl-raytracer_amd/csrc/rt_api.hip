@@ -497,7 +497,10 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
 
 extern "C" {
 
-const char* rt_version(void) { return "rt_hip gfx950 " __DATE__; }
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char* rt_version(void) { return "rt_hip gfx950 " RT_BUILD_ID " " __DATE__; }
 
 const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

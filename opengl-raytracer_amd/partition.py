@@ -50,3 +50,48 @@ def band_row_ranges(index: int, count: int, height: int, interleaved: bool = Fal
         out.append((r, min(r + 16, height)))
         r += 16 * count
     return out
+
+
+def render_partitioned(*, rank: int, world: int, steps: int, height: int, render, start_reduce, finish,
+                       mode: str = "samples", reduce_bands: int = 1, first_step: int = 0):
+    """This rank's share of a partitioned accumulation and the collective that closes it; the renderer and the
+    collective are passed in, so the same code runs on RCCL with the HIP library and on gloo with a CPU renderer.
+
+      render(frame_base, frame_stride, frames, band, rows)   enqueue these frames into the rank's buffer; band is None
+                                                             or (index, count) of a CONTIGUOUS band, rows its pixel-row
+                                                             range (r0, r1); in 'samples' mode the buffer receives SUMS
+      start_reduce(rows) -> handle                           start the sum-reduce of buffer[r0:r1] to rank 0 (may be
+                                                             asynchronous)
+      finish(handle)                                         wait for it
+
+    mode 'samples' (weak scaling): rank g renders frameCount (first_step+s)*world + g for s in [0, steps).  The closing
+    reduce costs time in proportion to the rows reduced, whatever the number of frames summed in them, so the image is
+    cut into `reduce_bands` contiguous row bands that are finished one after the other: the reduce of band b travels
+    while band b+1 renders, and only the last band's reduce (1/reduce_bands of the bytes) is exposed.  Bands are
+    bit-identical to the whole image (seeds use global pixel indices).  Rank 0 must scale the reduced sums by
+    1 / (steps * world) afterwards.
+
+    mode 'tiles' (strong scaling): every rank renders the same `steps` frames, restricted to its INTERLEAVED band
+    (band_row_ranges(rank, world, height, True)), running mean; the buffers are zero elsewhere, so one sum-reduce of
+    the whole image is the gather.  The band passed to render is then (rank, world) and rows is None.
+
+    Returns the list of row ranges reduced."""
+    if mode == "tiles":
+        render(first_step, 1, steps, (rank, world), None)
+        finish(start_reduce((0, height)))
+        return [(0, height)]
+    if mode != "samples":
+        raise ValueError("mode must be 'samples' or 'tiles'")
+    base, stride, frames = rank_frames(rank, world, first_step, steps)
+    count = max(1, min(int(reduce_bands), (height + 7) // 8))
+    pending, done = [], []
+    for b in range(count):
+        rows = band_rows(b, count, height)
+        if rows[1] <= rows[0]:
+            continue
+        render(base, stride, frames, None if count == 1 else (b, count), rows)
+        pending.append(start_reduce(rows))
+        done.append(rows)
+    for h in pending:
+        finish(h)
+    return done

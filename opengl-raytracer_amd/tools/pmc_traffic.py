@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""Turns the FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh into profiles/pmc_traffic.json, the file
-bench.py reads for roofline.traffic.
+"""Turns the PMC passes of tools/profile_bench.sh into profiles/pmc_traffic.json, the file bench.py reads for
+roofline.traffic / roofline.hbm / roofline.l2.
 
-Units and corrections (MI355X guide, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies
-128-byte requests at 64 bytes, i.e. reads exactly half the bytes of wide 16-B-per-lane reads, so it is
-doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  The path kernels issue 16-B-per-lane accesses (scattered,
-not streaming), for which the factor is uncalibrated: the raw value is kept next to the corrected one.
-Infinity-Cache hits are counted as traffic by these counters, so the number is an upper bound on HBM bytes.
+The file is stamped with the build id of the library that was profiled (the "build" field bench.py printed in those
+runs, i.e. the hash of the kernel sources); bench.py quotes the figures only when its own library has the same id.
 
-The figures are stored per launch of the profiled run and per frame (bench.py scales the latter to the launches of its
-own run); they describe the workload the profile was taken on, named in "_workload".
+Units and corrections (MI355X guide, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
+128-byte requests at 64 bytes, i.e. reads exactly half the bytes of wide 16-B-per-lane reads, so it is doubled;
+WRITE_SIZE is exact for 16-B-per-lane stores.  The path kernels issue 16-B-per-lane accesses (scattered, not
+streaming), for which the factor is uncalibrated: the raw value is kept next to the corrected one.  Infinity-Cache hits
+are counted as traffic by these counters, so the number is an upper bound on HBM bytes.
+L2 view: TCP_TCC_READ_REQ_sum + TCP_TCC_WRITE_REQ_sum are the requests the L1s send to the L2s, counted at 64 bytes each
+(the 16-byte-per-lane loads of a record fetch coalesce to one 64-byte request per record); TCC_HIT / (TCC_HIT + TCC_MISS)
+is the L2 hit rate.
+
+Only launches of <frames per launch> frames are wanted: run profile_bench.sh with --steps and --warmup that are
+multiples of it (bench.py then issues nothing but full launches); the few odd ones are dropped by keeping the upper half
+of the launches of each kernel.
 
 usage: pmc_traffic.py <gpurun_out/prof_TAG> <frames per launch> [out.json] [workload]
 """
@@ -22,31 +29,54 @@ import sys
 
 CLASS = {"k_paths": "paths", "k_accumulate": "accumulate", "k_mega": "mega", "k_extend": "extend", "k_shade": "shade",
          "k_tail": "tail", "k_generate": "generate"}
+WANTED = ("FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum")
+
+
+def upper_half_mean(v):
+    v = sorted(v)
+    k = v[len(v) // 2:]
+    return sum(k) / len(k)
 
 
 def main():
     d, frames = sys.argv[1], int(sys.argv[2])
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "profiles", "pmc_traffic.json")
+    workload = sys.argv[4] if len(sys.argv) > 4 else "dragon80k_1080p"
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                if row["Counter_Name"] not in WANTED or "<true" in row["Kernel_Name"]:   # not the counting instantiation
                     continue
                 for key, cls in CLASS.items():
                     if key in row["Kernel_Name"]:
                         vals[cls][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    workload = sys.argv[4] if len(sys.argv) > 4 else "dragon80k_1080p"
-    res = {"_source": os.path.basename(d.rstrip("/")), "_frames_per_launch": frames, "_workload": workload,
-           "_formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, largest launches only"}
+    builds = set()
+    for path in glob.glob(os.path.join(d, "*.json")):
+        try:
+            with open(path) as f:
+                builds.add(json.loads(f.read().strip().splitlines()[-1]).get("build"))
+        except (OSError, ValueError, IndexError):
+            pass
+    builds.discard(None)
+    if len(builds) != 1:
+        sys.exit(f"the bench outputs under {d} name {sorted(builds)} builds; need exactly one")
+    res = {"_source": os.path.basename(d.rstrip("/")), "_build": builds.pop(), "_frames_per_launch": frames, "_workload": workload,
+           "_formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; l2_bytes = (TCP_TCC_READ_REQ + TCP_TCC_WRITE_REQ) * 64; "
+                       "per launch of _frames_per_launch frames (upper half of the launches), divided by that for per frame"}
     for cls, c in vals.items():
-        # launches of the warm-up may be shorter: keep the launches with the largest write volume
-        f, w = sorted(c.get("FETCH_SIZE", [0.0])), sorted(c.get("WRITE_SIZE", [0.0]))
-        fk, wk = f[len(f) // 2:], w[len(w) // 2:]
-        fetch, write = sum(fk) / len(fk), sum(wk) / len(wk)
-        res[cls] = {"fetch_kib_raw": round(fetch, 1), "write_kib": round(write, 1),
-                    "hbm_bytes_per_launch": round((2 * fetch + write) * 1024),
-                    "hbm_bytes_per_frame": round((2 * fetch + write) * 1024 / frames)}
+        e = {}
+        if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+            fetch, write = upper_half_mean(c.get("FETCH_SIZE", [0.0])), upper_half_mean(c.get("WRITE_SIZE", [0.0]))
+            e.update(fetch_kib_raw=round(fetch, 1), write_kib=round(write, 1), hbm_bytes_per_launch=round((2 * fetch + write) * 1024),
+                     hbm_bytes_per_frame=round((2 * fetch + write) * 1024 / frames))
+        if "TCP_TCC_READ_REQ_sum" in c:
+            rd, wr = upper_half_mean(c["TCP_TCC_READ_REQ_sum"]), upper_half_mean(c.get("TCP_TCC_WRITE_REQ_sum", [0.0]))
+            e.update(l2_read_req=round(rd), l2_write_req=round(wr), l2_bytes_per_frame=round((rd + wr) * 64 / frames))
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            h, m = upper_half_mean(c["TCC_HIT_sum"]), upper_half_mean(c["TCC_MISS_sum"])
+            e.update(l2_hit_rate=round(h / (h + m), 4) if h + m > 0 else None)
+        res[cls] = e
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))

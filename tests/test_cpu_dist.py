@@ -19,16 +19,21 @@ def test_partition_is_exact(pkg):
         partition.rank_frames(2, 2, 0, 1)
 
 
-def test_two_rank_sum_reduce_matches_sequential_mean(tmp_path):
+@pytest.mark.parametrize("reduce_bands", [1, 3])
+def test_two_rank_sum_reduce_matches_sequential_mean(tmp_path, reduce_bands):
+    """partition.render_partitioned (what bench.py runs on RCCL) under gloo with the oracle as renderer: one reduce of
+    the whole image, and the image finished in three row bands whose reduces overlap the next band's rendering."""
     out = tmp_path / "result.npz"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", OMP_NUM_THREADS="2")
+    port = str(29641 + 10 * reduce_bands)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(ROOT, "tests", "dist_worker.py"), "3", str(out)]
+           "--master-port", port, os.path.join(ROOT, "tests", "dist_worker.py"), "3", str(out), "samples", str(reduce_bands)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = np.load(out)
     assert float(res["err"]) < 1e-6            # sum/N vs running mean: fp32 rounding only
     assert float(res["rays"]) == float(res["rays_seq"])   # every frame rendered exactly once
+    assert int(res["calls"]) == reduce_bands and bool(res["same_as_unbanded"])
 
 
 def test_two_rank_tile_partition_gathers_the_exact_image(tmp_path):
