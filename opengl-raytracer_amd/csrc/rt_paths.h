@@ -418,6 +418,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     float d1 = box_dist(p.o, p.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
                     float d2 = box_dist(p.o, p.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
                     int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
+                    // Diagnostic builds only (tools/pad_sensitivity.sh): N independent vector or scalar no-ops per inner-node
+                    // step, to measure what one more instruction in this loop costs.
+#ifdef PT_PAD_VNOP
+                    asm volatile(".rept " PT_PAD_VNOP "\n\tv_nop\n\t.endr" ::: "memory");
+#endif
+#ifdef PT_PAD_SNOP
+                    asm volatile(".rept " PT_PAD_SNOP "\n\ts_nop 0\n\t.endr" ::: "memory");
+#endif
                     // counting builds and waves with a lane at the spill area take the C++ tail
                     if (!COUNT && __builtin_amdgcn_ballot_w64(sp >= PT_STACK) == 0ull) {
                         pt_inner_tail_lds(d1, d2, r1, r2, stack_lds, best, sp, cur);
