@@ -1120,10 +1120,25 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_parents(BuildState s, int nu
 
 // One lane per node; lanes of leaves recompute the leaf's box from its triangles and walk up: the second lane to
 // arrive at an inner node (arrival counter) owns both finished children and continues, the first one stops.
-// The boxes travel between lanes on different XCDs (separate L2s).  A device-scope fence per step would write back
-// and invalidate whole caches (measured: 59 ms for 15 M nodes); instead the boxes are written and read with
-// device-scope relaxed atomics (write-through / cache-bypassing accesses), and the arrival counter is bumped only
-// after those stores have been acknowledged.
+//
+// Memory ordering.  The two children of a node are in general finished by lanes on different XCDs, whose L2s are not
+// coherent with each other.  The textbook form -- release on the first arriver's counter update, acquire on the second's
+// -- makes hipcc emit a whole-L2 write-back (buffer_wbl2 sc1) and invalidate (buffer_inv sc1) around every counter
+// update: 59 ms for 15 M nodes with fences, 33 ms per refit with an __ATOMIC_ACQ_REL counter (-DRT_REFIT_ACQ_REL) against 2.3 ms.
+// What is needed is much less, because only the six floats of one box travel:
+//   * boxes are written with agent-scope atomic stores: global_store_dword ... sc1, which writes through the XCD's L2 to
+//     the memory-side coherence point instead of staying dirty in it;
+//   * s_waitcnt vmcnt(0) then holds the lane until those stores are acknowledged, i.e. visible device-wide; only after
+//     that it issues the arrival counter's fetch_add (an agent-scope RMW, performed at the coherence point, so exactly
+//     one of the two arrivers reads 1);
+//   * the lane that reads 1 knows the sibling's stores were acknowledged before the sibling's fetch_add was issued; it
+//     reads the sibling box with agent-scope atomic loads: global_load_dword ... sc1, which miss its own L2 on purpose
+//     and fetch from the coherence point.  A GPU lane issues in order and does not speculate past the branch on the
+//     counter's value, so these loads cannot start before the fetch_add has returned.
+// The compiler is kept from moving the box accesses across the counter update by the asm statement (a "memory" clobber)
+// before it and the signal fence after it.  Everything above is gfx942/gfx950 cache behaviour, not the HIP memory model:
+// tests/test_gpu_build.py checks after every refit of the 15.8 M-node tree that each inner box is the exact union of
+// its children's, so a toolchain that broke the assumption would fail there first.
 __device__ __forceinline__ void refit_store(float4* p, float x, float y, float z) {
     float* f = (float*)p;
     __hip_atomic_store(f + 0, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1163,7 +1178,12 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_refit(BuildState s, int cur,
         const int p = s.nparent[node];
         if (p < 0) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the box has reached the coherence point before the arrival does
+#ifdef RT_REFIT_ACQ_REL
+        if (__hip_atomic_fetch_add(&s.nflag[p], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+#else
         if (__hip_atomic_fetch_add(&s.nflag[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+#endif
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);  // compiler only: the sibling loads stay behind the counter update
         const int sib = s.nchild[p] + (s.nchild[p] == node ? 1 : 0);
         float x, y, z;
         refit_load(&s.nmin[sib], x, y, z);

@@ -7,8 +7,17 @@
 // Display, where wanted, is a plain download of the frame; here the last frame is written as PFM/PPM (the image
 // is stored bottom row first, as GL textures are; PFM keeps that order, PPM is flipped).
 //
+//   * "mode:N" in the script is the keys 1-4 (main.cpp:232-247): switch the render mode and restart the accumulation.
+//
+// Multi-GPU split for C++ hosts (one process per GPU, no counterpart in the reference): --rank r --world n renders this
+// rank's share of every accumulation and writes it as a partial image; tools/combine_partials.py (or one ncclReduce /
+// gather in a host that links RCCL) puts the shares together.
+//   --partition samples  rank r renders the frames f of each accumulation with f mod n == r and writes their SUM
+//   --partition tiles    rank r renders its interleaved band (stripes of 16 rows) of every frame, zeros elsewhere
+//
 // usage: rt_headless <scene.obj> [--size W H] [--frames N] [--pos x y z] [--pitch p] [--yaw y] [--mode 1..4]
-//                    [--script "w:0.5,a:0.2,yaw:0.1,pitch:-0.2,wait:8;..."] [--batch] [--out image.pfm|.ppm]
+//                    [--script "w:0.5,a:0.2,yaw:0.1,pitch:-0.2,mode:3,wait:8;..."] [--batch] [--out image.pfm|.ppm]
+//                    [--device d] [--rank r --world n [--partition samples|tiles]]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -29,6 +38,7 @@ struct Step {
     float w = 0, a = 0, s = 0, d = 0;  // seconds each key is held
     double dyaw = 0, dpitch = 0;       // mouse look (radians)
     int wait = 1;                      // frames rendered after this input
+    int mode = 0;                      // 1..4: render-mode key pressed (0: none)
 };
 
 static std::vector<Step> parse_script(const std::string& text) {
@@ -51,6 +61,7 @@ static std::vector<Step> parse_script(const std::string& text) {
             else if (k == "yaw") st.dyaw = v;
             else if (k == "pitch") st.dpitch = v;
             else if (k == "wait") st.wait = std::max(1, (int)v);
+            else if (k == "mode") st.mode = (int)v;
         }
         out.push_back(st);
     }
@@ -95,7 +106,8 @@ int main(int argc, char** argv) {
     }
     std::string obj = argv[1], out_path, script;
     int W = 1920, H = 1080, frames = 64, mode = RT_MODE_RENDER;
-    bool batch = false;
+    bool batch = false, tiles = false;
+    int rank = 0, world = 1, device = 0;
     Vec3 cameraPos = CAMERA_START_POS;
     double cameraPitch = 0.0, cameraYaw = 0.0;
     for (int i = 2; i < argc; i++) {
@@ -110,11 +122,20 @@ int main(int argc, char** argv) {
         else if (a == "--script") { need(1); script = argv[++i]; }
         else if (a == "--out") { need(1); out_path = argv[++i]; }
         else if (a == "--batch") batch = true;
+        else if (a == "--rank") { need(1); rank = std::atoi(argv[++i]); }
+        else if (a == "--world") { need(1); world = std::atoi(argv[++i]); }
+        else if (a == "--device") { need(1); device = std::atoi(argv[++i]); }
+        else if (a == "--partition") { need(1); tiles = std::string(argv[++i]) == "tiles"; }
     }
+    if (world < 1 || rank < 0 || rank >= world) {
+        std::fprintf(stderr, "error: --rank %d out of range for --world %d\n", rank, world);
+        return 1;
+    }
+    const bool partitioned = world > 1;
     try {
         SceneData* sceneData = loadScene(obj);
         auto t0 = std::chrono::steady_clock::now();
-        Raytracer* rt = raytraceInit(sceneData, W, H);
+        Raytracer* rt = raytraceInit(sceneData, W, H, device);
         std::cout << "Raytracer initialised in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()
                   << " seconds" << std::endl;
         size_t bytes = (size_t)W * H * 4 * sizeof(float);
@@ -133,6 +154,10 @@ int main(int argc, char** argv) {
         for (size_t si = 0; si < steps.size(); si++) {
             const Step& st = steps[si];
             bool clearAccumulatedFrames = si > 0 || st.w || st.a || st.s || st.d || st.dyaw != 0 || st.dpitch != 0;
+            if (st.mode >= RT_MODE_RENDER && st.mode <= RT_MODE_REFLECTIONS) {  // keys 1-4, main.cpp:232-247
+                mode = st.mode;
+                clearAccumulatedFrames = true;
+            }
             // processInput: translate along the camera axes with the rotation of the previous frame
             cameraPos = {cameraPos[0], cameraPos[1], cameraPos[2]};
             Vec3 mv = mat_mul(cameraRotation, {CAMERA_MOVE_SPEED * (st.d - st.a), 0.0f, CAMERA_MOVE_SPEED * (st.w - st.s)});
@@ -142,7 +167,22 @@ int main(int argc, char** argv) {
             cameraYaw += st.dyaw;
             rt_host_camera_rotation(cameraPitch, cameraYaw, cameraRotation.data());
             if (clearAccumulatedFrames) frameCount = 0;
-            if (batch && mode == RT_MODE_RENDER) {
+            if (partitioned) {
+                if (mode != RT_MODE_RENDER) throw std::runtime_error("--world > 1 supports render mode 1 only");
+                if (frameCount == 0) HIP_OK(hipMemset(currentFrame, 0, bytes));  // a fresh accumulation: sums and bands start from zero
+                if (tiles) {
+                    raytraceAccumulatePart(rt, cameraPos, cameraRotation, frameCount, 1, st.wait, false, rank, world, currentFrame);
+                } else {
+                    // the frames f of [frameCount, frameCount + wait) with f mod world == rank
+                    const int end = frameCount + st.wait;
+                    const int first = frameCount + ((rank - frameCount) % world + world) % world;
+                    if (first < end)
+                        raytraceAccumulatePart(rt, cameraPos, cameraRotation, first, world, (end - first + world - 1) / world, true, 0, 0,
+                                               currentFrame);
+                }
+                frameCount += st.wait;
+                totalFrames += st.wait;
+            } else if (batch && mode == RT_MODE_RENDER) {
                 // same pixels, but the library may render the frames of one call concurrently
                 raytraceAccumulate(rt, cameraPos, cameraRotation, frameCount, st.wait, currentFrame);
                 frameCount += st.wait;

@@ -67,6 +67,16 @@ void raytraceAccumulate(Raytracer* rt, Vec3 cameraPos, Mat3 cameraRotation, int 
     check(rt, rt_render_device(rt->ctx, &cam, &p, d_accum), "rt_render_device");
 }
 
+void raytraceAccumulatePart(Raytracer* rt, Vec3 cameraPos, Mat3 cameraRotation, int frameBase, int frameStride, int frames,
+                            bool sum, int bandIndex, int bandCount, float* d_accum) {
+    rt_camera cam = make_camera(cameraPos, cameraRotation);
+    rt_params p = make_params(rt, RT_MODE_RENDER, frameBase, frames);
+    p.frame_stride = (uint32_t)frameStride;
+    if (sum) p.flags |= RT_FLAG_SUM;
+    if (bandCount > 0) p.band = ((uint32_t)bandIndex << 16) | (uint32_t)bandCount | RT_BAND_INTERLEAVED;
+    check(rt, rt_render_device(rt->ctx, &cam, &p, d_accum), "rt_render_device");
+}
+
 void raytraceShutdown(Raytracer* rt) {
     if (!rt) return;
     rt_destroy(rt->ctx);

@@ -37,4 +37,11 @@ void raytrace(Raytracer* rt, Vec3 cameraPos, Mat3 cameraRotation, int renderMode
               const float* d_prevFrame, float* d_outFrame);
 // render(scene, camera, spp) -> framebuffer: `frames` dispatches from frameBase accumulated in d_accum.
 void raytraceAccumulate(Raytracer* rt, Vec3 cameraPos, Mat3 cameraRotation, int frameBase, int frames, float* d_accum);
+// One GPU's share of a partitioned accumulation (no counterpart in the reference, which knows one GPU):
+//   samples  frames frameBase, frameBase + frameStride, ... summed into d_accum (RT_FLAG_SUM); the ranks' buffers are
+//            added (ncclReduce, or a file combiner) and divided by the total frame count;
+//   tiles    bandCount > 0: the running mean of consecutive frames, restricted to the interleaved band bandIndex of
+//            bandCount (stripes of 16 pixel rows dealt round-robin); the ranks' rows are gathered.
+void raytraceAccumulatePart(Raytracer* rt, Vec3 cameraPos, Mat3 cameraRotation, int frameBase, int frameStride, int frames,
+                            bool sum, int bandIndex, int bandCount, float* d_accum);
 void raytraceShutdown(Raytracer* rt);

@@ -218,3 +218,37 @@ def test_host_code_is_clean_under_sanitizers():
         r = subprocess.run([exe, os.path.join(FIXTURES, name + ".obj")], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="2"))
         assert r.returncode == 0 and "san_check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_combine_partials_tool(tmp_path):
+    """tools/combine_partials.py on synthetic partial images: the tile gather takes every row from its owner, the sample
+    combine is sum / frames."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "opengl-raytracer_amd", "tools"))
+    import combine_partials as cp
+    from opengl_raytracer_amd import partition
+    rng = np.random.RandomState(1)
+    h, w, world = 50, 8, 3
+    full = rng.uniform(0, 1, (h, w, 3)).astype(np.float32)
+    files = []
+    for r in range(world):
+        part = np.zeros_like(full)
+        for r0, r1 in partition.band_row_ranges(r, world, h, True):
+            part[r0:r1] = full[r0:r1]
+        f = tmp_path / f"t{r}.pfm"
+        cp.write_pfm(str(f), part)
+        files.append(str(f))
+    out = tmp_path / "tiles.pfm"
+    tool = os.path.join(ROOT, "opengl-raytracer_amd", "tools", "combine_partials.py")
+    assert subprocess.run([sys.executable, tool, "tiles", str(out)] + files, capture_output=True).returncode == 0
+    assert np.array_equal(cp.read_pfm(str(out)), full)
+    sums = [rng.uniform(0, 5, (h, w, 3)).astype(np.float32) for _ in range(world)]
+    files = []
+    for r, s_ in enumerate(sums):
+        f = tmp_path / f"s{r}.pfm"
+        cp.write_pfm(str(f), s_)
+        files.append(str(f))
+    out = tmp_path / "samples.pfm"
+    assert subprocess.run([sys.executable, tool, "samples", "12", str(out)] + files, capture_output=True).returncode == 0
+    assert np.allclose(cp.read_pfm(str(out)), (sums[0] + sums[1] + sums[2]) / 12.0, rtol=1e-6)

@@ -320,6 +320,67 @@ def test_headless_driver_loop_semantics(pkg, oracle, scenes, tmp_path, batch):
     assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
 
 
+def _headless(args, timeout=180):
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "opengl-raytracer_amd", "host", "rt_headless")
+    if not os.path.exists(exe):
+        pytest.skip("host/rt_headless not built")
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_headless_script_mode_keys(pkg, oracle, scenes, tmp_path):
+    """Keys 1-4 of the reference (main.cpp:232-247) as "mode:N" script items: the render mode changes and the
+    accumulation restarts.  Two frames in mode 1, then key 3 and two frames of the box-test heat map; back to mode 1."""
+    import os
+    from conftest import FIXTURES
+    obj = os.path.join(FIXTURES, "teapot.obj")
+    out = tmp_path / "m3.pfm"
+    _headless([obj, "--size", "320", "180", "--script", "wait:2;mode:3,wait:2", "--out", str(out)])
+    cam = pkg.make_camera()
+    want, _ = oracle.render(scenes("teapot"), cam, pkg.make_params(320, 180, frames=2, render_mode=3))
+    assert np.array_equal(bits(_read_pfm(out)), bits(np.ascontiguousarray(want[..., :3])))
+    out = tmp_path / "m1.pfm"
+    _headless([obj, "--size", "320", "180", "--script", "mode:4,wait:1;mode:1,wait:3", "--out", str(out)])
+    want, _ = oracle.render(scenes("teapot"), cam, pkg.make_params(320, 180, frames=3))
+    assert np.array_equal(bits(_read_pfm(out)), bits(np.ascontiguousarray(want[..., :3])))
+
+
+@pytest.mark.parametrize("mode", ["samples", "tiles"])
+def test_headless_rank_world_partition(pkg, oracle, scenes, tmp_path, mode):
+    """The multi-GPU split of the C++ host on one GPU: three ranks run one after the other, each writes its partial
+    image, tools/combine_partials.py puts them together.  Tiles: bit-equal to the unpartitioned image; samples: equal to
+    the running mean up to fp32 rounding."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT, FIXTURES
+    obj = os.path.join(FIXTURES, "teapot.obj")
+    world, frames = 3, 7
+    parts = []
+    for r in range(world):
+        part = tmp_path / f"part{r}.pfm"
+        _headless([obj, "--size", "320", "184", "--script", f"yaw:0.1,wait:{frames}", "--rank", str(r), "--world", str(world),
+                   "--partition", mode, "--out", str(part)])
+        parts.append(str(part))
+    out = tmp_path / "combined.pfm"
+    tool = os.path.join(ROOT, "opengl-raytracer_amd", "tools", "combine_partials.py")
+    cmd = [sys.executable, tool, mode] + ([str(frames)] if mode == "samples" else []) + [str(out)] + parts
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = _read_pfm(out)
+    want, _ = oracle.render(scenes("teapot"), pkg.make_camera(yaw=0.1), pkg.make_params(320, 184, frames=frames))
+    want = np.ascontiguousarray(want[..., :3])
+    if mode == "tiles":
+        assert np.array_equal(bits(got), bits(want))
+    else:
+        err = float(np.sqrt(((got.astype(np.float64) - want) ** 2).sum() / (want.astype(np.float64) ** 2).sum()))
+        assert err < 1e-6
+
+
 def test_config0_teapot_primary_plus_one_bounce(pkg, oracle, gpu_ctx, scenes):
     """BASELINE configs[0]: teapot, 1920x1080, 1 spp, primary + 1 diffuse bounce (ray_bounces = 2)."""
     scene = scenes("teapot")
