@@ -135,12 +135,6 @@ def main() -> int:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
-    # One real (non-default) stream carries everything: the library's accumulate kernels, torch's fills and scales, and
-    # the point the collectives are ordered against.  (rt_set_stream(NULL) means "the context's own stream", so torch's
-    # default stream, whose handle is 0, cannot be shared with the library.)
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-
     pkg = entry.load_package()
     from opengl_raytracer_amd import partition
     obj, cam_pos, W, H = WORKLOADS[args.workload]
@@ -160,7 +154,12 @@ def main() -> int:
     cam = pkg.make_camera(pos=cam_pos)
     ctx = pkg.RenderContext(local_rank)
     ctx.upload_scene(scene)
-    ctx.set_stream(stream.cuda_stream)
+    # One stream carries everything: the library's accumulate kernels, torch's fills and scales, and the point the
+    # collectives are ordered against -- the context's own stream, handed to torch as an external stream.  (Creating a
+    # torch.cuda.Stream instead makes torch allocate its pool of 32 streams, which then share the process's 4 hardware
+    # queues with the library's internal streams.)
+    stream = torch.cuda.ExternalStream(ctx.get_stream(), device=dev)
+    torch.cuda.set_stream(stream)
     build_id = pkg.build_id()
 
     # without torch.distributed the frames accumulate with the reference's running mean; under it (also with a single
@@ -415,8 +414,8 @@ def run_dynamic(args, pkg, partition, torch, dist, dev, rank, world, local_rank,
     col = pkg.make_colours(1, f.shape[0])
     cam = pkg.make_camera(pos=cam_pos)
     ctx = pkg.RenderContext(local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
+    stream = torch.cuda.ExternalStream(ctx.get_stream(), device=dev)
+    torch.cuda.set_stream(stream)
     ctx.build_scene_device(v, f, col, download=False)
     d_rest = torch.from_numpy(v).to(dev)
     d_v = torch.empty_like(d_rest)

@@ -125,8 +125,12 @@ int rt_destroy(rt_context* ctx);
  * With ctx == NULL returns the message of the last failed rt_create of this thread. */
 const char* rt_last_error(const rt_context* ctx);
 /* Use the caller's hipStream_t (passed as void*) for all subsequent work; NULL restores
- * the context's own stream. */
+ * the context's own stream.  (A NULL handle therefore never means HIP's legacy default stream: a caller that wants the
+ * library's work there passes hipStreamLegacy, whose handle is not NULL.) */
 int rt_set_stream(rt_context* ctx, void* hip_stream);
+/* The hipStream_t the context currently issues its work on (its own unless rt_set_stream changed it), so that a caller
+ * can enqueue its own kernels and copies in order with the library's instead of creating another stream. */
+int rt_get_stream(rt_context* ctx, void** out_hip_stream);
 /* Blocks until all work issued on the context's stream has finished. */
 int rt_synchronize(rt_context* ctx);
 

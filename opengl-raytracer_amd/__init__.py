@@ -113,6 +113,7 @@ HIP_SYMBOLS = [
     "rt_destroy",
     "rt_last_error",
     "rt_set_stream",
+    "rt_get_stream",
     "rt_synchronize",
     "rt_upload_scene",
     "rt_get_normals",
@@ -180,6 +181,7 @@ def load_hip() -> C.CDLL:
         lib.rt_last_error.argtypes = [vp]
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_set_stream.argtypes = [vp, vp]
+        lib.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
         lib.rt_synchronize.argtypes = [vp]
         lib.rt_upload_scene.argtypes = [vp, C.POINTER(RtScene)]
         lib.rt_get_normals.argtypes = [vp, c_float_p]
@@ -396,6 +398,11 @@ class RenderContext:
 
     def set_stream(self, stream_handle: int):
         self._check(self.lib.rt_set_stream(self.ctx, C.c_void_p(stream_handle)), "rt_set_stream")
+
+    def get_stream(self) -> int:
+        h = C.c_void_p()
+        self._check(self.lib.rt_get_stream(self.ctx, C.byref(h)), "rt_get_stream")
+        return h.value or 0
 
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.ctx), "rt_synchronize")

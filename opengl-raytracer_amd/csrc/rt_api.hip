@@ -144,6 +144,10 @@ struct rt_context {
     // the defaults for tuning runs
     int tune_min_trav = PT_MIN_TRAV, tune_min_service = PT_MIN_SERVICE, tune_w_inner = PT_W_INNER, tune_w_leaf = PT_W_LEAF;
     int tune_cache = -1;  // >= 0: stage at most this many records in LDS
+    // workgroups per CU of a launch that renders a single frame: with one, the launches of two consecutive frames are
+    // resident side by side for their whole duration and each fills the issue slots the other's drain leaves idle
+    int tune_frame_blocks = 1;
+    int tune_frame_chunk = 1;                  // PathsArgs::chunk of such a launch
 
     unsigned long long* d_counters = nullptr;
     unsigned char* scratch_ptr = nullptr;  // this device's copy of the static scratch array (rt_raytrace_frame_noalloc)
@@ -418,6 +422,7 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.min_service = c->tune_min_service;
     a.w_inner = c->tune_w_inner;
     a.w_leaf = c->tune_w_leaf;
+    a.chunk = nframes == 1 ? (uint32_t)c->tune_frame_chunk : 1u;
     if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
     a.samples = nullptr;
     a.spill = nullptr;
@@ -426,7 +431,8 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
 }
 
 static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, hipStream_t st) {
-    dim3 grid(c->num_cus * PT_BLOCKS_PER_CU), blk(PT_BLOCK);
+    // (the spill area is sized for the full grid; a smaller grid uses a prefix of it)
+    dim3 grid(c->num_cus * (a.num_frames == 1 ? c->tune_frame_blocks : PT_BLOCKS_PER_CU)), blk(PT_BLOCK);
 #define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, st, c->sc, dc, a)
     if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
     else { if (fix) PATHS(false, true); else PATHS(false, false); }
@@ -531,8 +537,20 @@ int rt_create(int device_id, rt_context** out_ctx) {
         rt_destroy(c);
         return rc;
     }
+    // The internal streams have the caller's default priority.  Streams of one priority share a small pool of hardware
+    // queues (4 per process by default): in a process that holds many streams -- PyTorch creates 32 with its first
+    // torch.cuda.Stream -- an internal stream can land on the hardware queue of the other one or of the caller's stream,
+    // and launches that are meant to overlap then run one after the other (frame-by-frame loop 0.54 -> 0.67 ms per
+    // frame).  Streams of another priority come from another pool (RT_TUNE_LANE_PRIORITY = 1 lowest / -1 highest), but
+    // with the lowest priority a process that also runs RCCL collectives hung on the GPU box (the collective's queue
+    // waits on an event of a queue that is never scheduled), so this is a tuning knob, not the default; callers that
+    // can should issue their own work on the context's stream (rt_get_stream) instead of adding streams.
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    int lane_prio = 0;
+    if (const char* ev = getenv("RT_TUNE_LANE_PRIORITY")) lane_prio = atoi(ev) < 0 ? prio_high : (atoi(ev) > 0 ? prio_low : 0);
     for (int k = 0; k < RT_LANES; k++) {
-        if ((e = hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking)) != hipSuccess ||
+        if ((e = hipStreamCreateWithPriority(&c->lane_stream[k], hipStreamNonBlocking, lane_prio)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming)) != hipSuccess) {
             int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
@@ -545,6 +563,8 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) c->tune_min_trav = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) c->tune_min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) c->tune_cache = atoi(e);
+    if (const char* e = getenv("RT_TUNE_FRAME_BLOCKS")) c->tune_frame_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_FRAME_CHUNK")) c->tune_frame_chunk = atoi(e);
     // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
     // traverse while some wait for a refill would send the wave back and forth without progress
     auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -552,6 +572,8 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->tune_min_service = clamp(c->tune_min_service, 1, 64);
     c->tune_w_inner = clamp(c->tune_w_inner, 1, 64);
     c->tune_w_leaf = clamp(c->tune_w_leaf, 1, 64);
+    c->tune_frame_blocks = clamp(c->tune_frame_blocks, 1, PT_BLOCKS_PER_CU);
+    c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
@@ -605,6 +627,13 @@ int rt_set_stream(rt_context* c, void* hip_stream) {
     if (!c) return RT_EINVAL;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+
+int rt_get_stream(rt_context* c, void** out_hip_stream) {
+    if (!c) return RT_EINVAL;
+    if (!out_hip_stream) return fail(c, RT_EINVAL, "out_hip_stream is NULL");
+    *out_hip_stream = (void*)c->stream;
     return RT_OK;
 }
 

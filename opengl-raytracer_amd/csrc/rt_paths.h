@@ -67,6 +67,7 @@ struct PathsArgs {
     int cache_recs;                 // records actually staged (<= PT_CACHE)
     int min_trav, min_service;      // phase-switch thresholds (lanes)
     int w_inner, w_leaf;            // an inner step runs when w_inner * (lanes at inner nodes) >= w_leaf * (lanes at leaves)
+    uint32_t chunk;                 // consecutive grabs of a workgroup take `chunk` consecutive items (1: every grab its own round)
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
     size_t spill_stride;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     uint32_t k = 0;
                     if ((tid & 63) == 0) k = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                    tile_g = xcd_slot + k * gridDim.x;
+                    tile_g = a.chunk == 1u ? xcd_slot + k * gridDim.x : ((k / a.chunk) * gridDim.x + xcd_slot) * a.chunk + k % a.chunk;
                     tile_off = 0;
                     if (tile_g >= a.total_tiles) exhausted = true;
                 }
