@@ -247,6 +247,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     float best = RT_INF;
     Counters cn = {0, 0, 0, 0, 0};
     unsigned long long paths = 0;
+
 #ifdef PT_DIAG
     unsigned long long dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 // iteration counters (even k): only the first active lane counts; lane sums (odd k): every active lane adds 1
@@ -416,9 +417,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         cn.pops++;
                         cn.box += 2;
                     }
+                    int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
                     float d1 = box_dist(p.o, p.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
                     float d2 = box_dist(p.o, p.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-                    int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
                     // Diagnostic builds only (tools/pad_sensitivity.sh): N independent vector or scalar no-ops per inner-node
                     // step, to measure what one more instruction in this loop costs.
 #ifdef PT_PAD_VNOP
