@@ -102,6 +102,9 @@ def main() -> int:
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true", help="non-default: refresh invDir after bounces")
+    ap.add_argument("--reuse-primary", action="store_true",
+                    help="non-default, a separate workload: RT_FLAG_REUSE_PRIMARY, the primary hits are traced once and every frame "
+                         "starts at the first bounce; Mrays/s then counts the rays actually traced, compare by fps")
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"],
                     help="N > 1: 'samples' = each GPU renders its own frames (weak scaling, the default); 'tiles' = every "
                          "GPU renders its horizontal band of every frame (strong scaling)")
@@ -171,6 +174,8 @@ def main() -> int:
     base_flags = pkg.RT_FLAG_SUM if sum_mode else 0
     if args.fix_invdir:
         base_flags |= pkg.RT_FLAG_FIX_INVDIR
+    if args.reuse_primary:
+        base_flags |= pkg.RT_FLAG_REUSE_PRIMARY
     if args.pipeline == "megakernel":
         base_flags |= pkg.RT_FLAG_MEGAKERNEL
         reduce_bands = 1   # bands are a feature of the default pipeline
@@ -299,7 +304,7 @@ def main() -> int:
     dom_ops_per_launch = algorithmic_lane_ops(dom_counters) / n_launch
     frames_per_launch = args.steps / n_launch  # whole-image frames (a launch over a band counts by its share of the rows)
 
-    pmc, pmc_why = load_pmc(args.workload, names[dominant], build_id, args.fix_invdir)
+    pmc, pmc_why = load_pmc(args.workload, names[dominant], build_id, args.fix_invdir or args.reuse_primary)
     traffic = hbm = l2 = None
     if pmc is not None:
         traffic = round(pmc["hbm_bytes_per_frame"] * frames_per_launch)
@@ -315,8 +320,8 @@ def main() -> int:
         value = total_rays / elapsed / 1e6
         tlane = dom_ops_per_launch / dom_s / 1e12
         out = {
-            "metric": "Mrays/s, 80K-tri dragon stand-in 1080p 1spp" if args.workload.startswith("dragon80k_1080p")
-            else f"Mrays/s, {args.workload}",
+            "metric": ("Mrays/s, 80K-tri dragon stand-in 1080p 1spp" if args.workload.startswith("dragon80k_1080p")
+                       else f"Mrays/s, {args.workload}") + (" (primary hits reused: rays actually traced)" if args.reuse_primary else ""),
             "value": round(value, 2),
             "unit": "Mrays/s",
             "fps": round(frames_total / elapsed, 2),
@@ -334,7 +339,9 @@ def main() -> int:
                             f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
                             f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}"
                             + (", one call of the boundary per frame with ping-pong buffers (the reference's loop, main.cpp:183-203)"
-                               if frame_loop else ""),
+                               if frame_loop else "")
+                            + (", RT_FLAG_REUSE_PRIMARY: primary hits traced once per camera, not per frame (NOT the reference's "
+                               "work per frame; separate workload)" if args.reuse_primary else ""),
                 "pipeline": args.pipeline,
                 "frames_total": frames_total,
                 "parallelism": (f"tile-partition x{world}" if tiles else f"sample-partition x{world}") if world > 1 else "single GPU",

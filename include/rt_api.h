@@ -55,6 +55,13 @@ extern "C" {
                                      is the persistent path kernel, which renders batches of frames
                                      concurrently.  All pipelines produce identical pixels. */
 
+#define RT_FLAG_REUSE_PRIMARY 0x20u /* OPT-IN shortcut, not what the reference does: the reference shoots the same primary ray
+                                     for a pixel in every frame (no jitter, raytrace.glsl:279-288), so while camera, image
+                                     size and scene stand still its closest hit is the same.  With this flag the hits are
+                                     traced once (kept in the context until camera, size, band or scene change) and every
+                                     path starts at its first bounce.  Pixels are bit-identical; rt_counters() then counts the
+                                     rays actually traced (the primary pass once + bounce rays).  Default pipeline only. */
+
 /* Scene in the layout the reference uploads (raytrace.cpp:38-54, scene-loader.h:7-15):
  *   nodes    num_nodes x 12 floats, AlignedMat3 {min.xyz,_}{max.xyz,_}{isLeaf,a,b,_};
  *            leaf iff |isLeaf-1| <= 1e-4, a..b inclusive triangle range, else child ids

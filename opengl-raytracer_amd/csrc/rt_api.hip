@@ -129,6 +129,14 @@ struct rt_context {
     int cache_recs = 0;           // inner-node records that are laid out breadth-first at the front
     float4* d_samples = nullptr;  // [frames of one launch][pixels] staging
     size_t samples_bytes = 0;
+    // RT_FLAG_REUSE_PRIMARY: closest hits of the primary rays of the last (camera, image size, band, scene) they were
+    // traced for; later launches with the same key start their paths from them
+    float2* d_phits = nullptr;
+    size_t phits_pixels = 0;
+    bool phits_valid = false;
+    DCamera phits_cam{};
+    uint32_t phits_band = 0;
+    hipEvent_t phits_ready = nullptr;  // recorded on the context's stream after the pass that fills d_phits
     uint2* d_pspill = nullptr;    // stack spill area, one copy per pipeline slot
     size_t pspill_entries = 0;
     // Launches of the path kernel are pipelined: consecutive launches (the frames of a frame-by-frame loop, the batches
@@ -219,6 +227,7 @@ static void free_scene(rt_context* c) {
     c->bd.out_cap = 0;
     c->built_nodes = 0;
     c->has_scene = false;
+    c->phits_valid = false;
 }
 
 static void free_buffers(rt_context* c) {
@@ -236,6 +245,9 @@ static void free_buffers(rt_context* c) {
     c->samples_bytes = 0;
     dfree(c->d_pspill);
     c->pspill_entries = 0;
+    dfree(c->d_phits);
+    c->phits_pixels = 0;
+    c->phits_valid = false;
 }
 
 // Brackets one launch with events when profiling is on.
@@ -295,6 +307,9 @@ static int check_render_args(rt_context* c, const rt_camera* cam, const rt_param
     if (p->rays_per_pixel == 0) return fail(c, RT_EINVAL, "rays_per_pixel must be at least 1");
     if (p->render_mode < RT_MODE_RENDER || p->render_mode > RT_MODE_REFLECTIONS)
         return fail(c, RT_EINVAL, "render_mode must be 1..4");
+    if ((p->flags & RT_FLAG_REUSE_PRIMARY) && ((p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) || p->render_mode != RT_MODE_RENDER ||
+                                              p->rays_per_pixel != 1 || p->ray_bounces == 0))
+        return fail(c, RT_EINVAL, "RT_FLAG_REUSE_PRIMARY is supported by the default pipeline only (render mode 1, rays_per_pixel 1)");
     if (p->band) {
         const uint32_t idx = p->band >> 16, cnt = p->band & 0x7fffu;
         if (cnt == 0 || idx >= cnt) return fail(c, RT_EINVAL, "band index %u out of range for %u bands", idx, cnt);
@@ -424,18 +439,26 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.w_leaf = c->tune_w_leaf;
     a.chunk = nframes == 1 ? (uint32_t)c->tune_frame_chunk : 1u;
     if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
+    a.hits = nullptr;
     a.samples = nullptr;
     a.spill = nullptr;
     a.spill_stride = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
     a.counters = (p->flags & RT_FLAG_COUNTERS) ? c->d_counters : nullptr;
 }
 
-static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, hipStream_t st) {
+static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, int pmode, hipStream_t st) {
     // (the spill area is sized for the full grid; a smaller grid uses a prefix of it)
-    dim3 grid(c->num_cus * (a.num_frames == 1 ? c->tune_frame_blocks : PT_BLOCKS_PER_CU)), blk(PT_BLOCK);
-#define PATHS(C_, F_) hipLaunchKernelGGL((k_paths<C_, F_>), grid, blk, 0, st, c->sc, dc, a)
-    if (count) { if (fix) PATHS(true, true); else PATHS(true, false); }
-    else { if (fix) PATHS(false, true); else PATHS(false, false); }
+    dim3 grid(c->num_cus * (a.num_frames == 1 && pmode != PM_PRIMARY ? c->tune_frame_blocks : PT_BLOCKS_PER_CU)), blk(PT_BLOCK);
+#define PATHS(C_, F_, M_) hipLaunchKernelGGL((k_paths<C_, F_, M_>), grid, blk, 0, st, c->sc, dc, a)
+    if (pmode == PM_PRIMARY) {  // no bounces in this pass: invDir handling does not matter
+        if (count) PATHS(true, false, PM_PRIMARY); else PATHS(false, false, PM_PRIMARY);
+    } else if (pmode == PM_REUSE) {
+        if (count) { if (fix) PATHS(true, true, PM_REUSE); else PATHS(true, false, PM_REUSE); }
+        else { if (fix) PATHS(false, true, PM_REUSE); else PATHS(false, false, PM_REUSE); }
+    } else {
+        if (count) { if (fix) PATHS(true, true, PM_TRACE); else PATHS(true, false, PM_TRACE); }
+        else { if (fix) PATHS(false, true, PM_TRACE); else PATHS(false, false, PM_TRACE); }
+    }
 #undef PATHS
 }
 
@@ -447,6 +470,42 @@ static void launch_k_accumulate(const rt_context* c, const rt_params* p, const B
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((bl.px.num_pixels + 255) / 256)), dim3(256), 0, c->stream,
                            (const float4*)a.samples, a.num_frames, a.pixels, bl.px, a.frame_base, a.frame_stride, sum ? 1u : 0u,
                            read_prev, prev, out);
+}
+
+// RT_FLAG_REUSE_PRIMARY: makes sure c->d_phits holds the closest hits of the primary rays of (camera, size, band, current
+// scene), tracing them in one pass of the path kernel on the context's stream if the last pass was for something else.
+// Every path launch that reads them waits on c->phits_ready.
+static int ensure_primary_hits(rt_context* c, const DCamera& dc, const rt_params* p, const BandLayout& bl) {
+    const size_t pixels = (size_t)p->width * p->height;
+    if (c->phits_valid && c->phits_pixels >= pixels && c->phits_band == p->band && std::memcmp(&c->phits_cam, &dc, sizeof dc) == 0)
+        return RT_OK;
+    if (pixels > c->phits_pixels) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // path kernels that read the old buffer are behind accumulates on this stream
+        dfree(c->d_phits);
+        c->phits_pixels = 0;
+        HIPCHK(c, hipMalloc(&c->d_phits, pixels * sizeof(float2)));
+        c->phits_pixels = pixels;
+    }
+    if (!c->phits_ready) HIPCHK(c, hipEventCreateWithFlags(&c->phits_ready, hipEventDisableTiming));
+    c->phits_valid = false;
+    PathsArgs a;
+    fill_paths_args(c, p, bl, 0u, 1u, 1u, a);
+    a.hits = c->d_phits;
+    a.spill = c->d_pspill;  // first spill copy: every earlier path kernel has finished by the time this stream gets here
+    // ... except those of internal streams whose accumulate has not been enqueued yet: there are none (a launch always
+    // enqueues its accumulate), but a launch on an internal stream may still be RUNNING behind an accumulate that waits
+    // for it, so wait for the internal streams explicitly
+    for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[k], 0));
+    {
+        LaunchTimer lt(c, RT_K_PATHS);
+        launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, false, PM_PRIMARY, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->phits_ready, c->stream));
+    std::memcpy(&c->phits_cam, &dc, sizeof dc);
+    c->phits_band = p->band;
+    c->phits_valid = true;
+    return RT_OK;
 }
 
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
@@ -465,8 +524,11 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     const uint32_t slot = pipelined ? (c->lane_next++ % RT_LANES) : 0u;
     hipStream_t pst = pipelined ? c->lane_stream[slot] : c->stream;
     const BandLayout bl = band_layout(p);
+    const bool reuse = (p->flags & RT_FLAG_REUSE_PRIMARY) != 0;
+    if (reuse && (rc = ensure_primary_hits(c, dc, p, bl)) != RT_OK) return rc;
     PathsArgs a;
     fill_paths_args(c, p, bl, frame_base, stride, nframes, a);
+    a.hits = reuse ? c->d_phits : nullptr;
     // every internal stream owns a fixed share of the staging area and its own spill copy, whatever the image size of
     // the launch: launches of different sizes that are in flight together never touch each other's samples
     a.samples = c->d_samples + (size_t)slot * (c->samples_bytes / RT_LANES / sizeof(float4));
@@ -478,9 +540,10 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
         // slot 0 and the first spill copy may still be in use by an internal stream's kernel
         for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamWaitEvent(pst, c->lane_done[k], 0));
     }
+    if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
     {
         LaunchTimer lt(c, RT_K_PATHS);
-        launch_k_paths(c, dc, a, count, fix, pst);
+        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : PM_TRACE, pst);
     }
     HIPCHK(c, hipGetLastError());
     if (pipelined) {
@@ -598,6 +661,7 @@ int rt_destroy(rt_context* c) {
     }
     free_scene(c);
     free_buffers(c);
+    if (c->phits_ready) (void)hipEventDestroy(c->phits_ready);
     for (void* p : c->ws_ptr)
         if (p) (void)hipFree(p);
     c->ws_ptr.clear();
@@ -889,6 +953,7 @@ static int build_core(rt_context* c) {
         bd.out_cap = nf;
     }
     c->has_scene = false;
+    c->phits_valid = false;
     bd.ref_valid = false;
 
     const uint32_t root_init[12] = {BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_POS_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF, BB_KEY_NEG_INF,
@@ -1056,6 +1121,7 @@ int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
     HIPCHK(c, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->last_build_ms, c->build_ev0, c->build_ev1);
     bd.ref_valid = false;
+    c->phits_valid = false;
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
     return RT_OK;
@@ -1222,6 +1288,7 @@ int rt_raytrace_frame_noalloc(rt_context* c, const rt_camera* cam, const rt_para
     if ((p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) || p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 ||
         p->ray_bounces == 0)
         return fail(c, RT_EINVAL, "rt_raytrace_frame_noalloc supports the default pipeline only (render mode 1, rays_per_pixel 1, ray_bounces >= 1)");
+    if (p->flags & RT_FLAG_REUSE_PRIMARY) return fail(c, RT_EINVAL, "rt_raytrace_frame_noalloc does not support RT_FLAG_REUSE_PRIMARY (its hit buffer is allocated)");
     const bool sum = (p->flags & RT_FLAG_SUM) != 0;
     if (!d_prev_frame && (sum || frame_count != 0)) return fail(c, RT_EINVAL, "d_prev_frame is NULL for frame %u", frame_count);
     // scratch layout: [staged samples of one frame: pixels x 16 B][pad to 256 B][spill: entries x threads x 8 B]
@@ -1245,7 +1312,7 @@ int rt_raytrace_frame_noalloc(rt_context* c, const rt_camera* cam, const rt_para
     // Both kernels go to the context's stream, so consecutive calls on one context run one after the other.  Nothing in
     // the scratch has to start at zero: the path kernel writes the sample of every pixel of the band and every spill
     // entry before anything reads it.
-    launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, (p->flags & RT_FLAG_FIX_INVDIR) != 0, c->stream);
+    launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, (p->flags & RT_FLAG_FIX_INVDIR) != 0, PM_TRACE, c->stream);
     HIPCHK(c, hipGetLastError());
     launch_k_accumulate(c, p, bl, a, (const float4*)d_prev_frame, (float4*)d_out_frame);
     HIPCHK(c, hipGetLastError());

@@ -55,6 +55,13 @@ static_assert(PT_SLOT_SHIFT > 0 && (1 << PT_SLOT_SHIFT) == PT_BLOCK * 8, "PT_BLO
 
 enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
 
+// What a launch of the path kernel does with primary rays.  The reference shoots the same primary ray for a pixel in every
+// frame (no jitter, raytrace.glsl:279-288), so while the camera stands still its closest hit is the same in every frame:
+//   PM_TRACE    every path traces its primary ray (what the reference does; the default)
+//   PM_PRIMARY  one pass over the image that traces only the primary rays and stores their closest hits
+//   PM_REUSE    every path starts from the stored hit of its pixel and traces only its bounce rays (RT_FLAG_REUSE_PRIMARY)
+enum { PM_TRACE = 0, PM_PRIMARY = 1, PM_REUSE = 2 };
+
 struct PathsArgs {
     uint32_t frame_base, frame_stride, num_frames;
     uint32_t bounces;
@@ -68,6 +75,7 @@ struct PathsArgs {
     int min_trav, min_service;      // phase-switch thresholds (lanes)
     int w_inner, w_leaf;            // an inner step runs when w_inner * (lanes at inner nodes) >= w_leaf * (lanes at leaves)
     uint32_t chunk;                 // consecutive grabs of a workgroup take `chunk` consecutive items (1: every grab its own round)
+    float2* hits;                   // [pixels] closest hit of every pixel's primary ray, (t, id bits): written in PM_PRIMARY, read in PM_REUSE
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
     size_t spill_stride;
@@ -183,7 +191,7 @@ __device__ __forceinline__ void pt_inner_tail_lds(float d1, float d2, int r1, in
         : "vcc", "scc", "v62", "v63", "memory");
 }
 
-template <bool COUNT, bool FIX>
+template <bool COUNT, bool FIX, int PMODE>
 __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k_paths(DScene sc, DCamera cam, PathsArgs a) {
     __shared__ uint2 s_stack[PT_STACK][PT_BLOCK];
     __shared__ float4 s_nodes[PT_CACHE * 4];
@@ -261,7 +269,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
         for (;;) {
             DIAG(4, 1);
             if (state == ST_DONE || (state == ST_NEED && !exhausted)) { DIAG(5, 1); }
-            if (state == ST_DONE) {
+            if (PMODE == PM_PRIMARY) {
+                if (state == ST_DONE) {  // num_frames is 1 in this mode: out_idx is the pixel index
+                    a.hits[out_idx] = make_float2(best, rt_u2f((uint32_t)best_id));
+                    state = ST_NEED;
+                }
+            } else if (state == ST_DONE) {
                 // sample = sky(dir.y) * throughput, evaluated by k_accumulate; a path that ends without
                 // reaching the sky (Russian roulette, bounce limit) contributes zero
                 float4 sample = make_float4(p.thr.x, p.thr.y, p.thr.z, p.d.y);
@@ -313,9 +326,19 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                             primary_ray(cam, gx, gy, p.o, p.d, p.inv);
                             p.seed = pixel_seed(cam, gx, gy, a.frame_base + f * a.frame_stride);
                             p.thr = rt_v3(1.0f, 1.0f, 1.0f);
-                            out_idx = f * a.pixels + (uint32_t)gy * (uint32_t)cam.width + (uint32_t)gx;
+                            const uint32_t pix = (uint32_t)gy * (uint32_t)cam.width + (uint32_t)gx;
+                            out_idx = f * a.pixels + pix;
                             bnc = 0;
-                            state = ST_NEW;
+                            if (PMODE == PM_REUSE) {
+                                // the primary ray's closest hit is known: the path goes straight to its first bounce (or the sky)
+                                const float2 h = a.hits[pix];
+                                best = h.x;
+                                best_id = (int)rt_f2u(h.y);
+                                cur = RT_REF_IDLE;
+                                state = ST_DONE;
+                            } else {
+                                state = ST_NEW;
+                            }
                             if (COUNT) paths++;
                         }
                     }

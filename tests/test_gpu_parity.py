@@ -248,6 +248,59 @@ def test_pipelined_frames_of_two_image_sizes_do_not_share_staging(pkg, oracle, g
         b.free()
 
 
+@pytest.mark.parametrize("fix", [False, True])
+def test_reuse_primary_is_bit_identical_and_traces_fewer_rays(pkg, oracle, gpu_ctx, scenes, fix):
+    """RT_FLAG_REUSE_PRIMARY (opt-in): the primary hits are traced once per (camera, size, scene) and every path starts at
+    its first bounce.  Same pixels as the oracle; the counters show the primary pass once plus the bounce rays; a camera
+    move, a scene swap and a frame-by-frame continuation all invalidate or reuse the stored hits correctly."""
+    W, H, n = 333, 217, 5
+    flags = pkg.RT_FLAG_REUSE_PRIMARY | (pkg.RT_FLAG_FIX_INVDIR if fix else 0)
+    base = pkg.RT_FLAG_FIX_INVDIR if fix else 0
+    for name in ("dragon80k", "teapot"):
+        scene = scenes(name)
+        gpu_ctx.upload_scene(scene)
+        for yaw in (0.0, 0.2):                       # the second camera must not see the first one's hits
+            cam = pkg.make_camera(yaw=yaw, **CAMERAS[name])
+            want, cnt_o = oracle.render(scene, cam, pkg.make_params(W, H, frames=n, flags=base))
+            gpu_ctx.reset_counters()
+            got = gpu_ctx.render(cam, pkg.make_params(W, H, frames=n, flags=flags | pkg.RT_FLAG_COUNTERS))
+            cnt = gpu_ctx.counters()
+            _assert_image_equal(got, want, f"{name} yaw={yaw} reuse")
+            # hits as in the oracle; the primary pass adds one "path" per pixel; rays = all rays minus (n - 1) x the
+            # primary rays (one per pixel and frame)
+            assert cnt[5] == cnt_o[5] + W * H and cnt[3] == cnt_o[3]
+            assert cnt[2] == cnt_o[2] - (n - 1) * W * H
+            plain = gpu_ctx.render(cam, pkg.make_params(W, H, frames=n, flags=flags))          # non-counting kernels
+            _assert_image_equal(plain, want, f"{name} yaw={yaw} reuse, no counters")
+        # frame-by-frame continuation with the same camera: the stored hits serve every call
+        cont = gpu_ctx.render(cam, pkg.make_params(W, H, frames=2, frame_base=n, flags=flags), got.copy())
+        want2, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=n + 2, flags=base))
+        _assert_image_equal(cont, want2, f"{name} continuation")
+    # one call per frame (the reference's loop): the first call traces the primary hits, the others reuse them
+    cam = pkg.make_camera(yaw=-0.1, **CAMERAS["teapot"])
+    bufs = [pkg.DeviceBuffer(W * H * 16), pkg.DeviceBuffer(W * H * 16)]
+    p1 = pkg.make_params(W, H, flags=flags)
+    for f in range(4):
+        gpu_ctx.raytrace_frame(cam, p1, f, bufs[(f + 1) & 1].ptr, bufs[f & 1].ptr)
+    gpu_ctx.synchronize()
+    want, _ = oracle.render(scenes("teapot"), cam, pkg.make_params(W, H, frames=4, flags=base))
+    _assert_image_equal(bufs[1].to_array((H, W, 4), np.float32), want, "frame loop with reuse")
+    for b in bufs:
+        b.free()
+    # bands and the flag together; other pipelines refuse it
+    cam = pkg.make_camera(**CAMERAS["teapot"])
+    whole = gpu_ctx.render(cam, pkg.make_params(W, H, frames=3, flags=flags))
+    union = np.zeros_like(whole)
+    from opengl_raytracer_amd import partition
+    for g in range(3):
+        part = gpu_ctx.render(cam, pkg.make_params(W, H, frames=3, flags=flags, band=(g, 3), interleaved=True))
+        for r0, r1 in partition.band_row_ranges(g, 3, H, True):
+            union[r0:r1] = part[r0:r1]
+    assert np.array_equal(bits(union), bits(whole))
+    with pytest.raises(RuntimeError):
+        gpu_ctx.render(cam, pkg.make_params(64, 64, flags=flags | pkg.RT_FLAG_MEGAKERNEL))
+
+
 def test_sample_partition_sum_matches_running_mean(pkg, gpu_ctx, scenes):
     """The multi-GPU decomposition on one GPU: G interleaved frame subsets summed, divided by the frame
     count, against the sequential running mean -- equal to fp32 rounding, far inside 1e-3."""
