@@ -10,6 +10,8 @@ Units and corrections (MI355X guide, HBM section): FETCH_SIZE and WRITE_SIZE are
 WRITE_SIZE is exact for 16-B-per-lane stores.  The path kernels issue 16-B-per-lane accesses (scattered, not
 streaming), for which the factor is uncalibrated: the raw value is kept next to the corrected one.  Infinity-Cache hits
 are counted as traffic by these counters, so the number is an upper bound on HBM bytes.
+Vector-memory address view: TCP_TOTAL_CACHE_ACCESSES_sum counts the cache-line accesses of the L1 (one per lane address
+that does not coalesce); TA_TA_BUSY_sum / SQ_BUSY_CU_CYCLES is the share of the CUs' busy time the address unit was occupied.
 L2 view: TCP_TCC_READ_REQ_sum + TCP_TCC_WRITE_REQ_sum are the requests the L1s send to the L2s, counted at 64 bytes each
 (the 16-byte-per-lane loads of a record fetch coalesce to one 64-byte request per record); TCC_HIT / (TCC_HIT + TCC_MISS)
 is the L2 hit rate.
@@ -29,7 +31,8 @@ import sys
 
 CLASS = {"k_paths": "paths", "k_accumulate": "accumulate", "k_mega": "mega", "k_extend": "extend", "k_shade": "shade",
          "k_tail": "tail", "k_generate": "generate"}
-WANTED = ("FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum")
+WANTED = ("FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum",
+          "TA_TA_BUSY_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_BUSY_CU_CYCLES")
 
 
 def upper_half_mean(v):
@@ -76,6 +79,11 @@ def main():
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
             h, m = upper_half_mean(c["TCC_HIT_sum"]), upper_half_mean(c["TCC_MISS_sum"])
             e.update(l2_hit_rate=round(h / (h + m), 4) if h + m > 0 else None)
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+            # vector-memory address unit: one lane address (one cache-line access) per cycle and CU
+            e.update(l1_accesses_per_frame=round(upper_half_mean(c["TCP_TOTAL_CACHE_ACCESSES_sum"]) / frames))
+        if "TA_TA_BUSY_sum" in c and "SQ_BUSY_CU_CYCLES" in c:
+            e.update(ta_busy_frac=round(upper_half_mean(c["TA_TA_BUSY_sum"]) / upper_half_mean(c["SQ_BUSY_CU_CYCLES"]), 4))
         res[cls] = e
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 around the SAME command the driver runs (python3 bench.py ...): one kernel-trace/stats run and the PMC
-# passes (HBM traffic: FETCH_SIZE, WRITE_SIZE; L2 view: TCP->TCC requests, TCC hits/misses), each in a run of its own.
+# passes (HBM traffic: FETCH_SIZE, WRITE_SIZE; L2 view: TCP->TCC requests, TCC hits/misses; vector-memory address unit),
+# each in a run of its own.
 # Then writes profiles/pmc_traffic.json, stamped with the build id of the profiled library, and a kernel summary.
 # Usage: profile_bench.sh <tag> <frames per launch> [bench.py args...]   (run from the repo root on the GPU box;
 # give --steps and --warmup as multiples of <frames per launch> so that every launch is a full one)
@@ -12,7 +13,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_under_trace.json" 2> "$out/trace.log" || { echo "trace run failed"; tail -5 "$out/trace.log"; exit 1; }
 i=0
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
   timeout -s KILL 300 rocprofv3 --pmc $pmc --output-format csv -d "$out/pmc$i" -- python3 bench.py --no-cpu-baseline "$@" > "$out/pmc$i.json" 2> "$out/pmc$i.log" || { echo "pmc pass $i failed"; tail -3 "$out/pmc$i.log"; exit 1; }
 done
