@@ -3,11 +3,14 @@
 # Run from the repository root on the GPU box.
 out=gpurun_out/bench_all.jsonl
 : > $out
-run() { echo "== bench.py $*" >&2; timeout -k 10 600 python bench.py --no-cpu-baseline "$@" 2>/dev/null >> $out || echo "{\"failed\": \"$*\"}" >> $out; }
+run() { echo "== bench.py $*" | tee -a gpurun_out/bench_all.progress >&2; timeout -k 10 600 python bench.py --no-cpu-baseline "$@" 2>/dev/null >> $out || echo "{\"failed\": \"$*\"}" >> $out; }
 run --steps 64 --warmup 8
 run --workload teapot_1080p --steps 64 --warmup 8
 run --workload dragon80k_4k --steps 256 --warmup 8
 run --workload dragon80k_1080p --fix-invdir --steps 64 --warmup 8
+run --workload dragon80k_1080p_frame_loop --steps 64 --warmup 8
+run --workload dragon80k_1080p --reuse-primary --steps 64 --warmup 8
+run --workload dragon80k_4k --reuse-primary --steps 256 --warmup 8
 run --workload dragon80k_1080p --pipeline megakernel --steps 32 --warmup 4
 run --workload dragon80k_1080p --pipeline wavefront --steps 32 --warmup 4
 run --workload grid9m_1080p --steps 16 --warmup 4
