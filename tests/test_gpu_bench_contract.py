@@ -61,11 +61,11 @@ def _run_bench(extra, launcher=()):
 
 def test_bench_under_torch_distributed_single_rank():
     """The N > 1 code path on one GPU: launched by torch.distributed.run with one rank, bench.py initialises RCCL,
-    renders with RT_FLAG_SUM in row bands, reduces every band to rank 0 and scales the sum.  The mean image must equal
+    renders with RT_FLAG_SUM (here in two row bands, the default is one), reduces every band to rank 0 and scales the sum.  The mean image must equal
     the one of the plain run (running mean) up to fp32 rounding, and the exposed reduce time must be small."""
     plain = _run_bench([])
     launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29655"]
-    d = _run_bench(["--gpus", "1"], launcher)
+    d = _run_bench(["--gpus", "1", "--reduce-bands", "2"], launcher)
     assert d["n_gpus"] == 1 and d["config"]["frames_total"] == 8
     assert d["rays_per_frame"] == plain["rays_per_frame"]
     for a, b in zip(d["image_mean_rgb"], plain["image_mean_rgb"]):
