@@ -227,17 +227,15 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def one_pass(target, flags, reduce=True, bounces=100):
-        partition.render_partitioned(rank=rank, world=world, steps=args.steps, height=H, render=make_render(target, flags, bounces),
+    def one_pass(target, flags, reduce=True, bounces=100, steps=None):
+        partition.render_partitioned(rank=rank, world=world, steps=args.steps if steps is None else steps, height=H,
+                                     render=make_render(target, flags, bounces),
                                      start_reduce=start_reduce if reduce else no_reduce, finish=finish, mode=mode,
                                      reduce_bands=reduce_bands)
 
     # ---- warm-up (untimed): W steps, and one pass through the collective --------------------------------
     if args.warmup:
-        saved = args.steps
-        args.steps = args.warmup
-        one_pass(bufs, base_flags)
-        args.steps = saved
+        one_pass(bufs, base_flags, steps=args.warmup)
     elif dist is not None:
         finish(start_reduce((0, H)))
     marks.clear()
