@@ -446,9 +446,12 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.counters = (p->flags & RT_FLAG_COUNTERS) ? c->d_counters : nullptr;
 }
 
-static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, int pmode, hipStream_t st) {
+// overlapped: the launch shares the chip with the launch before or after it (pipelined calls); a single-frame launch then
+// takes tune_frame_blocks workgroups per CU, any other launch fills the chip.
+static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, int pmode, bool overlapped,
+                           hipStream_t st) {
     // (the spill area is sized for the full grid; a smaller grid uses a prefix of it)
-    dim3 grid(c->num_cus * (a.num_frames == 1 && pmode != PM_PRIMARY ? c->tune_frame_blocks : PT_BLOCKS_PER_CU)), blk(PT_BLOCK);
+    dim3 grid(c->num_cus * (overlapped && a.num_frames == 1 ? c->tune_frame_blocks : PT_BLOCKS_PER_CU)), blk(PT_BLOCK);
 #define PATHS(C_, F_, M_) hipLaunchKernelGGL((k_paths<C_, F_, M_>), grid, blk, 0, st, c->sc, dc, a)
     if (pmode == PM_PRIMARY) {  // no bounces in this pass: invDir handling does not matter
         if (count) PATHS(true, false, PM_PRIMARY); else PATHS(false, false, PM_PRIMARY);
@@ -498,7 +501,7 @@ static int ensure_primary_hits(rt_context* c, const DCamera& dc, const rt_params
     for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[k], 0));
     {
         LaunchTimer lt(c, RT_K_PATHS);
-        launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, false, PM_PRIMARY, c->stream);
+        launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, false, PM_PRIMARY, false, c->stream);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->phits_ready, c->stream));
@@ -543,7 +546,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
     {
         LaunchTimer lt(c, RT_K_PATHS);
-        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : PM_TRACE, pst);
+        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : PM_TRACE, pipelined, pst);
     }
     HIPCHK(c, hipGetLastError());
     if (pipelined) {
@@ -1312,7 +1315,7 @@ int rt_raytrace_frame_noalloc(rt_context* c, const rt_camera* cam, const rt_para
     // Both kernels go to the context's stream, so consecutive calls on one context run one after the other.  Nothing in
     // the scratch has to start at zero: the path kernel writes the sample of every pixel of the band and every spill
     // entry before anything reads it.
-    launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, (p->flags & RT_FLAG_FIX_INVDIR) != 0, PM_TRACE, c->stream);
+    launch_k_paths(c, dc, a, (p->flags & RT_FLAG_COUNTERS) != 0, (p->flags & RT_FLAG_FIX_INVDIR) != 0, PM_TRACE, false, c->stream);
     HIPCHK(c, hipGetLastError());
     launch_k_accumulate(c, p, bl, a, (const float4*)d_prev_frame, (float4*)d_out_frame);
     HIPCHK(c, hipGetLastError());
