@@ -17,8 +17,16 @@
 //
 // usage: rt_headless <scene.obj> [--size W H] [--frames N] [--pos x y z] [--pitch p] [--yaw y] [--mode 1..4]
 //                    [--script "w:0.5,a:0.2,yaw:0.1,pitch:-0.2,mode:3,wait:8;..."] [--batch] [--out image.pfm|.ppm]
-//                    [--device d] [--rank r --world n [--partition samples|tiles]]
+//                    [--device d] [--rank r --world n [--partition samples|tiles]] [--rccl <id file>]
+//
+// --rccl <id file>: the ranks (one process per GPU, started by any launcher) combine their shares themselves with one RCCL
+// ncclReduce of the device frame buffers to rank 0, which scales the sum and writes --out; the 128-byte ncclUniqueId
+// travels through the named file (rank 0 writes it, the others wait for it).  librccl is loaded only in this mode.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -92,6 +100,66 @@ static void write_image(const std::string& path, const std::vector<float>& rgba,
     std::fclose(f);
 }
 
+// RCCL, loaded on demand (the library is half a gigabyte; the single-GPU driver should not pay for mapping it).
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+
+    void check(ncclResult_t r, const char* what) const {
+        if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + (GetErrorString ? GetErrorString(r) : "RCCL error"));
+    }
+    void load() {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) throw std::runtime_error(std::string("cannot load librccl: ") + dlerror());
+        auto sym = [&](const char* n) {
+            void* p = dlsym(lib, n);
+            if (!p) throw std::runtime_error(std::string("librccl lacks ") + n);
+            return p;
+        };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        Reduce = (decltype(Reduce))sym("ncclReduce");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    }
+    // rank 0 creates the id and publishes it through the file (written under another name, then renamed, so that a
+    // reader never sees half of it); the other ranks wait for the file
+    void init(const std::string& id_file, int rank, int world) {
+        load();
+        ncclUniqueId id;
+        if (rank == 0) {
+            check(GetUniqueId(&id), "ncclGetUniqueId");
+            const std::string tmp = id_file + ".tmp";
+            FILE* f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+            std::fclose(f);
+            if (std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
+        } else {
+            bool ok = false;
+            for (int tries = 0; tries < 1200 && !ok; tries++) {  // up to two minutes
+                FILE* f = std::fopen(id_file.c_str(), "rb");
+                if (f) {
+                    ok = std::fread(&id, sizeof id, 1, f) == 1;
+                    std::fclose(f);
+                }
+                if (!ok) usleep(100000);
+            }
+            if (!ok) throw std::runtime_error("no ncclUniqueId appeared in " + id_file);
+        }
+        check(CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    }
+    void shutdown() {
+        if (comm) (void)CommDestroy(comm);
+        comm = nullptr;
+    }
+};
+
 #define HIP_OK(call)                                                                                        \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
@@ -104,7 +172,7 @@ int main(int argc, char** argv) {
                              "[--mode m] [--script s] [--batch] [--out file]\n", argv[0]);
         return 1;
     }
-    std::string obj = argv[1], out_path, script;
+    std::string obj = argv[1], out_path, script, rccl_id_file;
     int W = 1920, H = 1080, frames = 64, mode = RT_MODE_RENDER;
     bool batch = false, tiles = false;
     int rank = 0, world = 1, device = 0;
@@ -126,13 +194,20 @@ int main(int argc, char** argv) {
         else if (a == "--world") { need(1); world = std::atoi(argv[++i]); }
         else if (a == "--device") { need(1); device = std::atoi(argv[++i]); }
         else if (a == "--partition") { need(1); tiles = std::string(argv[++i]) == "tiles"; }
+        else if (a == "--rccl") { need(1); rccl_id_file = argv[++i]; }
     }
     if (world < 1 || rank < 0 || rank >= world) {
         std::fprintf(stderr, "error: --rank %d out of range for --world %d\n", rank, world);
         return 1;
     }
-    const bool partitioned = world > 1;
+    const bool use_rccl = !rccl_id_file.empty();
+    const bool partitioned = world > 1 || use_rccl;  // with --rccl also a single rank goes through the sum + reduce + scale path
     try {
+        Rccl rccl;
+        if (use_rccl) {
+            HIP_OK(hipSetDevice(device));
+            rccl.init(rccl_id_file, rank, world);
+        }
         SceneData* sceneData = loadScene(obj);
         auto t0 = std::chrono::steady_clock::now();
         Raytracer* rt = raytraceInit(sceneData, W, H, device);
@@ -197,17 +272,29 @@ int main(int argc, char** argv) {
                 std::swap(currentFrame, prevFrame);  // currentFrame = the frame written last
             }
         }
+        if (use_rccl) {
+            // the one collective of the path: sum (samples) or gather (tiles: disjoint bands, zero elsewhere) to rank 0,
+            // on the stream the render was issued on
+            void* st = nullptr;
+            if (rt_get_stream(rt->ctx, &st) != RT_OK) throw std::runtime_error(rt_last_error(rt->ctx));
+            rccl.check(rccl.Reduce(currentFrame, currentFrame, (size_t)W * H * 4, ncclFloat, ncclSum, 0, rccl.comm, (hipStream_t)st), "ncclReduce");
+        }
         rt_synchronize(rt->ctx);
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
         std::cout << "Average FPS: " << totalFrames / secs << "\n";
-        if (!out_path.empty()) {
+        if (!out_path.empty() && (!use_rccl || rank == 0)) {
             std::vector<float> host((size_t)W * H * 4);
             HIP_OK(hipMemcpy(host.data(), currentFrame, bytes, hipMemcpyDeviceToHost));
+            if (use_rccl && !tiles) {  // sum of the frames of the last accumulation -> mean
+                const float scale = 1.0f / (float)frameCount;
+                for (float& v : host) v *= scale;
+            }
             write_image(out_path, host, W, H);
             std::cout << "wrote " << out_path << std::endl;
         }
         (void)hipFree(currentFrame);
         (void)hipFree(prevFrame);
+        rccl.shutdown();
         raytraceShutdown(rt);
         delete sceneData;
     } catch (const std::exception& e) {

@@ -434,6 +434,26 @@ def test_headless_rank_world_partition(pkg, oracle, scenes, tmp_path, mode):
         assert err < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["samples", "tiles"])
+def test_headless_rccl_reduce_single_rank(pkg, oracle, scenes, tmp_path, mode):
+    """The C++ host's own collective: rt_headless --rccl creates an RCCL communicator (here of one rank, the only size a
+    one-GPU box allows), renders its share with RT_FLAG_SUM / its band, calls ncclReduce on the device frame buffer on the
+    context's stream, and rank 0 scales and writes the image."""
+    import os
+    from conftest import FIXTURES
+    out = tmp_path / "rccl.pfm"
+    _headless([os.path.join(FIXTURES, "teapot.obj"), "--size", "320", "184", "--script", "yaw:0.1,wait:5", "--world", "1", "--rank", "0",
+               "--partition", mode, "--rccl", str(tmp_path / "nccl_id"), "--out", str(out)], timeout=300)
+    got = _read_pfm(out)
+    want, _ = oracle.render(scenes("teapot"), pkg.make_camera(yaw=0.1), pkg.make_params(320, 184, frames=5))
+    want = np.ascontiguousarray(want[..., :3])
+    if mode == "tiles":
+        assert np.array_equal(bits(got), bits(want))
+    else:
+        err = float(np.sqrt(((got.astype(np.float64) - want) ** 2).sum() / (want.astype(np.float64) ** 2).sum()))
+        assert err < 1e-6
+
+
 def test_config0_teapot_primary_plus_one_bounce(pkg, oracle, gpu_ctx, scenes):
     """BASELINE configs[0]: teapot, 1920x1080, 1 spp, primary + 1 diffuse bounce (ray_bounces = 2)."""
     scene = scenes("teapot")
