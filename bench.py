@@ -72,6 +72,13 @@ def algorithmic_lane_ops(c) -> float:
     return 27.0 * box + 60.0 * tri + 150.0 * rays
 
 
+def executed_lane_ops(c, culled: bool) -> float:
+    """Lane-ops of the traversal as it ran: the same weights on the executed counts, plus ~22 per box test for the cull
+    test that rides on every inner-node visit of the default pipeline (3 reciprocals, 12 sub/mul, 14 min/max, a compare)."""
+    box, tri, rays, hits, pops, paths = [float(x) for x in c]
+    return (27.0 + (22.0 if culled else 0.0)) * box + 60.0 * tri + 150.0 * rays
+
+
 def load_pmc(workload: str, kernel: str, build: str, fix_invdir: bool):
     """PMC figures per frame of `kernel` from profiles/pmc_traffic.json -- only if they were taken with THIS build of
     the library on THIS workload (the file carries the build id of the library that was profiled)."""
@@ -102,6 +109,8 @@ def main() -> int:
     ap.add_argument("--workload", default="dragon80k_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true", help="non-default: refresh invDir after bounces")
+    ap.add_argument("--no-cull", action="store_true",
+                    help="non-default: RT_FLAG_NO_CULL, traverse exactly the nodes the reference traverses")
     ap.add_argument("--reuse-primary", action="store_true",
                     help="non-default, a separate workload: RT_FLAG_REUSE_PRIMARY, the primary hits are traced once and every frame "
                          "starts at the first bounce; Mrays/s then counts the rays actually traced, compare by fps")
@@ -176,6 +185,8 @@ def main() -> int:
     base_flags = pkg.RT_FLAG_SUM if sum_mode else 0
     if args.fix_invdir:
         base_flags |= pkg.RT_FLAG_FIX_INVDIR
+    if args.no_cull:
+        base_flags |= pkg.RT_FLAG_NO_CULL
     if args.reuse_primary:
         base_flags |= pkg.RT_FLAG_REUSE_PRIMARY
     if args.pipeline == "megakernel":
@@ -271,13 +282,19 @@ def main() -> int:
         one_pass(scratch, flags | pkg.RT_FLAG_COUNTERS, reduce=False, bounces=bounces)
         return ctx.counters().astype(np.float64)
 
-    counters = count_pass(base_flags)
-    if dist is not None:
-        tot = torch.tensor(counters, dtype=torch.float64, device=dev)
+    # `counters`: the reference's traversal (its numBoxTests / numTriangleTests: the definition of the algorithmic work);
+    # `executed`: the traversal as the timed region ran it (the default pipeline skips subtrees a bounce ray cannot reach)
+    def all_ranks(c):
+        if dist is None:
+            return c
+        tot = torch.tensor(c, dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
-        counters_all = tot.cpu().numpy()
-    else:
-        counters_all = counters
+        return tot.cpu().numpy()
+
+    counters = count_pass(base_flags | pkg.RT_FLAG_NO_CULL)
+    executed = counters if args.no_cull else count_pass(base_flags)
+    culled = bool(executed[0] < counters[0])
+    counters_all, executed_all = all_ranks(counters), all_ranks(executed)
     total_rays = float(counters_all[2])
     frames_total = args.steps if tiles else args.steps * world
 
@@ -292,11 +309,12 @@ def main() -> int:
     # algorithmic work of the dominant kernel class alone: for the wavefront extend kernel that is the
     # traversal work of the first RT_WF_BOUNCES(=2) bounces, which a 2-bounce counting pass isolates
     if names[dominant] == "extend":
-        dom_counters = count_pass(base_flags, bounces=2)
+        dom_counters = count_pass(base_flags | pkg.RT_FLAG_NO_CULL, bounces=2)
         dom_counters[5] = 0.0  # the accumulator traffic belongs to the shade kernel
         dom_counters[3] = 0.0  # so do the normal/colour fetches
     else:
         dom_counters = counters.copy()
+    dom_executed = executed if names[dominant] == "paths" else dom_counters
     n_launch = max(1, int(launches[dominant]))
     dom_ms = float(ms[dominant]) / n_launch
     dom_s = dom_ms * 1e-3 if dom_ms > 0 else float("inf")
@@ -304,7 +322,7 @@ def main() -> int:
     dom_ops_per_launch = algorithmic_lane_ops(dom_counters) / n_launch
     frames_per_launch = args.steps / n_launch  # whole-image frames (a launch over a band counts by its share of the rows)
 
-    pmc, pmc_why = load_pmc(args.workload, names[dominant], build_id, args.fix_invdir or args.reuse_primary)
+    pmc, pmc_why = load_pmc(args.workload, names[dominant], build_id, args.fix_invdir or args.reuse_primary or args.no_cull)
     traffic = hbm = l2 = vmem = None
     if pmc is not None:
         traffic = round(pmc["hbm_bytes_per_frame"] * frames_per_launch)
@@ -344,6 +362,7 @@ def main() -> int:
                 "workload": f"{args.workload}: {obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
                             f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
                             f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}"
+                            + (", RT_FLAG_NO_CULL (the reference's literal traversal)" if args.no_cull else "")
                             + (", one call of the boundary per frame with ping-pong buffers (the reference's loop, main.cpp:183-203)"
                                if frame_loop else "")
                             + (", RT_FLAG_REUSE_PRIMARY: primary hits traced once per camera, not per frame (NOT the reference's "
@@ -369,12 +388,25 @@ def main() -> int:
                 "rays_per_path": round(total_rays / counters_all[5], 4),
                 "algorithmic_bytes": round(algorithmic_bytes(counters_all) / total_rays, 1),
                 "algorithmic_lane_ops": round(algorithmic_lane_ops(counters_all) / total_rays, 1),
+                "note": "the reference's own traversal of these rays (RT_FLAG_NO_CULL counting pass): the definition of the "
+                        "algorithmic work",
+            },
+            "executed_per_ray": {
+                "box_tests": round(executed_all[0] / total_rays, 3),
+                "tri_tests": round(executed_all[1] / total_rays, 3),
+                "node_pops": round(executed_all[4] / total_rays, 3),
+                "lane_ops": round(executed_lane_ops(executed_all, culled) / total_rays, 1),
+                "culled": culled,
+                "note": "the traversal as timed: same rays, same hits, same image; subtrees that a bounce ray's true line "
+                        "cannot reach are skipped (the reference walks them because its slab tests use the primary ray's "
+                        "stale invDir); lane_ops counts the cull test too",
             },
             "kernels_ms_per_frame": {names[k]: round(float(ms[k]) / args.steps, 4) for k in range(len(names)) if launches[k]},
             "image_mean_rgb": [round(x, 5) for x in image_mean],
             # The ceiling that binds this kernel is vector-instruction issue (the scene is cache-resident, HBM and L2
-            # are far from their peaks, there is no matrix work): frac is the share of the chip's fp32 lane-operations
-            # per second that went into the algorithm's own arithmetic.
+            # are far from their peaks, there is no matrix work): achieved = the arithmetic of the reference's traversal
+            # of these rays (27 lane-ops per box test, 60 per triangle test, 150 per ray, on the reference's own counts)
+            # per second; `executed` prices what the kernel ran instead.
             "roofline": {
                 "bound": "valu",
                 "kernel": names[dominant],
@@ -388,6 +420,11 @@ def main() -> int:
                 "frames_per_launch": round(frames_per_launch, 3),
                 "lane_ops_per_launch": round(dom_ops_per_launch, 0),
                 "frac_end_to_end": round(algorithmic_lane_ops(counters_all) / elapsed / VALU_PEAK_LANE_OPS / world, 4),
+                "executed": {"achieved": round(executed_lane_ops(dom_executed, culled) / n_launch / dom_s / 1e12, 3),
+                             "frac": round(executed_lane_ops(dom_executed, culled) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
+                             "frac_without_cull_tests": round(algorithmic_lane_ops(dom_executed) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
+                             "note": "achieved / frac above price the REFERENCE's traversal of these rays (its box and triangle "
+                                     "test counts) per second; these are the lane-ops the kernel actually ran"},
                 "hbm": hbm,
                 "l2": l2,
                 "vmem_address": vmem,

@@ -55,6 +55,14 @@ extern "C" {
                                      is the persistent path kernel, which renders batches of frames
                                      concurrently.  All pipelines produce identical pixels. */
 
+#define RT_FLAG_NO_CULL 0x40u      /* traverse exactly the nodes the reference traverses.  By default the path kernel skips
+                                     the subtree under a box that a bounce ray's TRUE line passes at a distance: with the
+                                     stale invDir (raytrace.glsl:247-254) the reference's slab tests follow the primary
+                                     ray's line instead, so it walks through subtrees none of whose triangles the ray can
+                                     hit.  Skipping them cannot change a pixel (the pad of the test covers the rounding of
+                                     the triangle test); it changes the work counters, which count what ran.  With this
+                                     flag they equal the reference's numBoxTests / numTriangleTests.  No effect with
+                                     RT_FLAG_FIX_INVDIR (the slab test then is the true one) or on the other pipelines */
 #define RT_FLAG_REUSE_PRIMARY 0x20u /* OPT-IN shortcut, not what the reference does: the reference shoots the same primary ray
                                      for a pixel in every frame (no jitter, raytrace.glsl:279-288), so while camera, image
                                      size and scene stand still its closest hit is the same.  With this flag the hits are

@@ -26,6 +26,7 @@ RT_FLAG_MEGAKERNEL = 0x4
 RT_FLAG_COUNTERS = 0x8
 RT_FLAG_WAVEFRONT = 0x10
 RT_FLAG_REUSE_PRIMARY = 0x20
+RT_FLAG_NO_CULL = 0x40
 RT_BAND_INTERLEAVED = 0x8000
 RT_NUM_COUNTERS = 6
 RT_NUM_KERNEL_CLASSES = 7

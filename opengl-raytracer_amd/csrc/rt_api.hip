@@ -150,6 +150,10 @@ struct rt_context {
 
     // scheduling parameters of the path kernel; the RT_TUNE_* environment variables (read once, at rt_create) override
     // the defaults for tuning runs
+    // Cull slack of the current scene (see cull_slack_of): twice the pad by which the path kernel widens a child box
+    // before it skips the subtree of a bounce ray that passes it at a distance; < 0: this scene is traversed uncut.
+    float cull_slack = -1.0f;
+    float tune_cull_slack = -2.0f;  // RT_TUNE_CULL_SLACK: >= -1 overrides the scene's value (diagnostics)
     int tune_min_trav = PT_MIN_TRAV, tune_min_service = PT_MIN_SERVICE, tune_w_inner = PT_W_INNER, tune_w_leaf = PT_W_LEAF;
     int tune_cache = -1;  // >= 0: stage at most this many records in LDS
     // workgroups per CU of a launch that renders a single frame: with one, the launches of two consecutive frames are
@@ -168,6 +172,32 @@ struct rt_context {
 };
 
 static thread_local std::string g_create_error;
+
+// Slack of the path kernel's cull test for a scene whose root box has diagonal D and whose triangles have edges
+// e1 = b - a, e2 = c - a with |e1| * |e2| <= m1 and |e1|, |e2| <= m2.
+//
+// The kernel skips the subtree under a child box when a bounce ray's true line (origin o inside the root box, direction
+// d, t >= 0) stays farther than `pad` from the box.  That never changes a result if no triangle inside the box can then
+// report a hit, i.e. if the triangle test of raytrace.glsl:79-110, evaluated in fp32, accepts a ray only when the ray
+// passes within `pad` of the triangle.  With u = 2^-24, E = RT_EPS and s = o - a (|s| <= D):
+//   the test rejects |det| < E, so the computed barycentrics and distance differ from the exact solution of
+//   o + t d = a + u e1 + v e2 by at most
+//     |du| <= (7.5 |s| |e2| + 6.6 |e1||e2|) u / E + 2u,   |dv| likewise with e1,   |dt| <= (7.5 |s| + 6.5 T) |e1||e2| u / E + 2u T
+//   (rounding of the two cross products, three dot products, the reciprocal and the products; T <= D + 2.04 m2 is the
+//   largest distance to a point of the triangle), which moves the computed hit point by no more than
+//     fp = (u / E) m1 (29 D + 26.5 m2) + 2u (D + 4.1 m2);
+//   the test accepts barycentrics up to E outside [0, 1]: another 2 E (|e1| + |e2|) <= 4 E m2;
+//   the stored edges are rounded differences (u m2), and the slab arithmetic of the cull test itself (a subtraction, an
+//   approximate reciprocal, a product) is off by at most 4u D per plane.
+// pad = 4 fp + 4 E m2 + u m2 + 8u D: the floating-point part carries a safety factor of 4.  The first-order bounds
+// need the relative error of det to be small, 6.5 u m1 / E << 1: scenes with m1 >= 2 (or a NaN anywhere) are not culled.
+static float cull_slack_of(double D, double m1, double m2) {
+    const double u = 1.0 / 16777216.0, E = (double)RT_EPS;
+    if (!(D >= 0.0) || !(m1 < 2.0) || !(m2 < 1e18) || !(D < 1e18)) return -1.0f;
+    const double fp = (u / E) * m1 * (29.0 * D + 26.5 * m2) + 2.0 * u * (D + 4.1 * m2);
+    const double pad = 4.0 * fp + 4.0 * E * m2 + u * m2 + 8.0 * u * D;
+    return (float)(2.0 * pad * 1.001);
+}
 
 static int fail(rt_context* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -435,6 +465,7 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
     a.min_trav = c->tune_min_trav;
     a.min_service = c->tune_min_service;
+    a.cull_slack = (p->flags & RT_FLAG_NO_CULL) ? -1.0f : (c->tune_cull_slack >= -1.0f ? c->tune_cull_slack : c->cull_slack);
     a.w_inner = c->tune_w_inner;
     a.w_leaf = c->tune_w_leaf;
     a.chunk = nframes == 1 ? (uint32_t)c->tune_frame_chunk : 1u;
@@ -629,6 +660,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) c->tune_min_trav = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) c->tune_min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) c->tune_cache = atoi(e);
+    if (const char* e = getenv("RT_TUNE_CULL_SLACK")) c->tune_cull_slack = (float)atof(e);  // -1: never cull
     if (const char* e = getenv("RT_TUNE_FRAME_BLOCKS")) c->tune_frame_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_CHUNK")) c->tune_frame_chunk = atoi(e);
     // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
@@ -801,8 +833,19 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     tris.reserve((size_t)T * 16);
     int root_ref = 0;
     auto as_f = [](int v) { return rt_u2f((uint32_t)v); };
+    // For the path kernel's cull test (cull_slack_of): the largest edge product and edge of any triangle, and whether
+    // every box lies inside its parent's and every triangle inside its leaf's.  The reference's builder guarantees the
+    // latter (bvh.cpp grows a box from its triangles); a caller's own tree that does not, or one with a NaN or infinite
+    // vertex, is traversed uncut.
+    double edge_prod_max = 0.0, edge_max = 0.0;
+    bool nested = true;
     for (int i = 0; i < V; i++) {
         const Visit& v = order[i];
+        const float* box = s->nodes + (size_t)12 * v.node;
+        if (v.parent >= 0) {
+            const float* pb = s->nodes + (size_t)12 * order[v.parent].node;
+            for (int j = 0; j < 3; j++) nested = nested && box[j] >= pb[j] && box[4 + j] <= pb[4 + j];
+        }
         int ref;
         if (v.leaf) {
             if (v.b < v.a) {
@@ -816,6 +859,14 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
                                      p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f,
                                      0.0f, 0.0f, 0.0f, 0.0f};
                     tris.insert(tris.end(), rec, rec + 16);
+                    for (int j = 0; j < 3; j++)
+                        nested = nested && p0[j] >= box[j] && p0[j] <= box[4 + j] && p1[j] >= box[j] && p1[j] <= box[4 + j] &&
+                                 p2[j] >= box[j] && p2[j] <= box[4 + j];
+                    const double l1 = std::sqrt((double)rec[4] * rec[4] + (double)rec[5] * rec[5] + (double)rec[6] * rec[6]);
+                    const double l2 = std::sqrt((double)rec[8] * rec[8] + (double)rec[9] * rec[9] + (double)rec[10] * rec[10]);
+                    if (!std::isfinite(l1) || !std::isfinite(l2)) nested = false;
+                    edge_prod_max = std::max(edge_prod_max, l1 * l2);
+                    edge_max = std::max(edge_max, std::max(l1, l2));
                 }
                 // leaves of a malformed scene may overlap; the records they expand to obey the same limit
                 if (tris.size() / 16 >= ((size_t)1 << 26)) return fail(c, RT_ELIMIT, "leaves expand to more than 2^26 - 1 triangle records");
@@ -880,10 +931,24 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     c->num_tris = T;
     c->max_depth = max_depth;
     c->cache_recs = cache_recs;
+    {
+        double diag2 = 0.0;
+        for (int k = 0; k < 3; k++) diag2 += ((double)s->nodes[4 + k] - s->nodes[k]) * ((double)s->nodes[4 + k] - s->nodes[k]);
+        c->cull_slack = nested ? cull_slack_of(std::sqrt(diag2), edge_prod_max, edge_max) : -1.0f;
+    }
     c->has_scene = true;
     // a deeper tree may need a larger spill area: force re-allocation on the next render
     if (c->max_depth > RT_LDS_STACK && (size_t)(c->max_depth - RT_LDS_STACK + 1) > c->spill_entries) free_buffers(c);
     return RT_OK;
+}
+
+// Cull slack of a device-built tree: its boxes are exact unions of what is below them, the triangle emit kernel has
+// reduced the edge maxima (a NaN among them reads back as a NaN).
+static float built_cull_slack(float4 rlo, float4 rhi, const float edge_max[2]) {
+    const double dx = (double)rhi.x - rlo.x, dy = (double)rhi.y - rlo.y, dz = (double)rhi.z - rlo.z;
+    if (!std::isfinite(edge_max[0]) || !std::isfinite(edge_max[1])) return -1.0f;
+    // the kernel's lengths are fp32: a relative 1e-6 covers their rounding
+    return cull_slack_of(std::sqrt(dx * dx + dy * dy + dz * dz), (double)edge_max[0] * 1.000001, (double)edge_max[1] * 1.000001);
 }
 
 // ---- GPU BVH build (rt_build.h) ---------------------------------------------------------------------------
@@ -1025,11 +1090,16 @@ static int build_core(rt_context* c) {
         return fail(c, RT_EDEVICE, "builder: %d nodes / %d records for %d faces", num_nodes, num_recs, nf);
     }
     hipLaunchKernelGGL(k_build_emit_recs, dim3((num_nodes + BB_BLOCK - 1) / BB_BLOCK), blk, 0, st, s, num_nodes, c->d_nodes);
-    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, s, cur, nf, bd.d_verts, bd.d_faces, bd.d_fcol, c->d_tris, c->d_shade);
+    uint32_t* const d_edge_max = (uint32_t*)(s.counters + 6);  // counters 6, 7: free after the level loop
+    BCHK(hipMemsetAsync(d_edge_max, 0, 2 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, s, cur, nf, bd.d_verts, bd.d_faces, bd.d_fcol, c->d_tris, c->d_shade,
+                       d_edge_max);
     BCHK(hipEventRecord(c->build_ev1, st));
     float4 rlo, rhi;
+    float edge_max[2];
     BCHK(hipMemcpyAsync(&rlo, s.nmin, sizeof rlo, hipMemcpyDeviceToHost, st));
     BCHK(hipMemcpyAsync(&rhi, s.nmax, sizeof rhi, hipMemcpyDeviceToHost, st));
+    BCHK(hipMemcpyAsync(edge_max, d_edge_max, sizeof edge_max, hipMemcpyDeviceToHost, st));
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->last_build_ms, c->build_ev0, c->build_ev1);
@@ -1042,6 +1112,7 @@ static int build_core(rt_context* c) {
     c->sc.shade = c->d_shade;
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
+    c->cull_slack = built_cull_slack(rlo, rhi, edge_max);
     c->sc.root_ref = num_nodes == 1 ? ~0 : 0;  // a single leaf starts at triangle 0; otherwise the root owns record 0
     c->sc.num_tris = nf;
     c->num_tris = nf;
@@ -1115,16 +1186,22 @@ int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
     HIPCHK(c, hipMemsetAsync(bd.s.nflag, 0, (size_t)num_nodes * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_build_refit, grid_n, blk, 0, st, bd.s, bd.cur, num_nodes, bd.d_verts, bd.d_faces);
     hipLaunchKernelGGL(k_build_emit_recs, grid_n, blk, 0, st, bd.s, num_nodes, c->d_nodes);
-    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, bd.s, bd.cur, nf, bd.d_verts, bd.d_faces, bd.d_fcol, c->d_tris, c->d_shade);
+    uint32_t* const d_edge_max = (uint32_t*)(bd.s.counters + 6);
+    HIPCHK(c, hipMemsetAsync(d_edge_max, 0, 2 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_build_emit_tris, grid_t, blk, 0, st, bd.s, bd.cur, nf, bd.d_verts, bd.d_faces, bd.d_fcol, c->d_tris, c->d_shade,
+                       d_edge_max);
     HIPCHK(c, hipEventRecord(c->build_ev1, st));
     float4 rlo, rhi;
+    float edge_max[2];
     HIPCHK(c, hipMemcpyAsync(&rlo, bd.s.nmin, sizeof rlo, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(&rhi, bd.s.nmax, sizeof rhi, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(edge_max, d_edge_max, sizeof edge_max, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->last_build_ms, c->build_ev0, c->build_ev1);
     bd.ref_valid = false;
     c->phits_valid = false;
+    c->cull_slack = built_cull_slack(rlo, rhi, edge_max);
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
     return RT_OK;

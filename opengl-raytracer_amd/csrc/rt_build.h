@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_recs(BuildState s, int 
 // triangle records in leaf order and the shade records (normal as shaders/normals.glsl:13-19 computes it, colour)
 __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int cur, int n, const float* verts,
                                                               const uint32_t* faces, const float4* face_colours, float4* tris,
-                                                              float4* shade) {
+                                                              float4* shade, uint32_t* edge_max) {
     int k = blockIdx.x * BB_BLOCK + threadIdx.x;
     if (k >= n) return;
     uint32_t t = s.order[cur][k];
@@ -1234,6 +1234,26 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int 
     q[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, rt_u2f((uint32_t)k));
     q[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0f);
     q[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // edge_max[0] = max |e1| * |e2|, edge_max[1] = max(|e1|, |e2|) over all triangles, as float bits: non-negative floats
+    // order like their bit patterns, and a NaN (above every number) marks a scene with a NaN vertex.  The path kernel's
+    // cull pad is derived from the two (cull_slack_of in rt_api.hip).
+    {
+        const float l1 = rt_sqrt(rt_dot(rt_sub(b, a), rt_sub(b, a))), l2 = rt_sqrt(rt_dot(rt_sub(c, a), rt_sub(c, a)));
+        uint32_t m1 = rt_f2u(l1 * l2) & 0x7fffffffu, m2 = rt_f2u(l1) & 0x7fffffffu, m3 = rt_f2u(l2) & 0x7fffffffu;
+        m2 = m2 > m3 ? m2 : m3;
+        const unsigned long long live = __ballot(1);  // the last wave is partly past the end
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)m1, off, 64), o2 = (uint32_t)__shfl_xor((int)m2, off, 64);
+            if ((live >> ((threadIdx.x & 63) ^ off)) & 1ull) {
+                m1 = m1 > o1 ? m1 : o1;
+                m2 = m2 > o2 ? m2 : o2;
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&edge_max[0], m1);
+            atomicMax(&edge_max[1], m2);
+        }
+    }
     const rt_vec3 nrm = rt_normalize(rt_cross(rt_sub(a, b), rt_sub(a, c)));
     const float4 col = face_colours[t];
     shade[2 * (size_t)k] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);

@@ -78,6 +78,7 @@ struct PathsArgs {
     int min_trav, min_service;      // phase-switch thresholds (lanes)
     int w_inner, w_leaf;            // an inner step runs when w_inner * (lanes at inner nodes) >= w_leaf * (lanes at leaves)
     uint32_t chunk;                 // consecutive grabs of a workgroup take `chunk` consecutive items (1: every grab its own round)
+    float cull_slack;               // < 0: off; else 2 * (pad of every box) for the true-direction cull of the inner-node step
     float2* hits;                   // [pixels] closest hit of every pixel's primary ray, (t, id bits): written in PM_PRIMARY, read in PM_REUSE
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
@@ -192,6 +193,20 @@ __device__ __forceinline__ void pt_inner_tail_lds(float d1, float d2, int r1, in
         : [save] "=&s"(save), [np] "=&s"(np), [addr] "=&v"(addr), [rn] "=&v"(rn), [dn] "=&v"(dn), [sp] "+v"(sp), [cur] "+v"(cur)
         : [d1] "v"(d1), [d2] "v"(d2), [r1] "v"(r1), [r2] "v"(r2), [stack0] "v"(stack0), [best] "v"(best), [idle] "v"(RT_REF_IDLE), [shift] "n"(PT_SLOT_SHIFT)
         : "vcc", "scc", "v62", "v63", "memory");
+}
+
+// d, or RT_INF when the ray o + t * dir (t >= 0; ix, iy, iz ~ 1 / dir) passes the box at a distance: with
+// slack = 2 * pad * max |1 / dir_k|, `hi + slack < lo` implies that the three slab intervals of the box widened by pad on
+// every side have no common point in t >= 0 (each widened interval reaches at most slack / 2 beyond the plain one).
+// v_min / v_max drop a NaN operand (0 * inf: the origin on a plane the ray runs parallel to); an infinite slack (a zero
+// direction component, or a primary ray) never culls.
+__device__ __forceinline__ float cull_dist(float d, rt_vec3 o, float ix, float iy, float iz, float slack, float nx, float ny,
+                                           float nz, float xx, float xy, float xz) {
+    const float ax = (nx - o.x) * ix, ay = (ny - o.y) * iy, az = (nz - o.z) * iz;
+    const float bx = (xx - o.x) * ix, by = (xy - o.y) * iy, bz = (xz - o.z) * iz;
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+    const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return hi + slack < lo ? RT_INF : d;
 }
 
 template <bool COUNT, bool FIX, int PMODE>
@@ -446,6 +461,19 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                     int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
                     float d1 = box_dist(p.o, p.inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
                     float d2 = box_dist(p.o, p.inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                    // A bounce ray's slab tests run with the primary ray's stale 1/dir (raytrace.glsl:247-254 never refreshes
+                    // it), so they lead the traversal along the primary ray's line, through subtrees the ray itself never
+                    // comes near.  A child whose box, widened by the scene's pad, the ray's TRUE line misses cannot hold a
+                    // hit: it is dropped here (distance = infinity: neither pushed nor entered), which leaves every result
+                    // as it is and saves about a third of all node visits.  Primary rays are exempt: their slab test is
+                    // the true one, and their origin may be far outside the scene, where the pad does not cover rounding.
+                    if (!FIX && PMODE != PM_PRIMARY && a.cull_slack >= 0.0f) {
+                        const float ix = __builtin_amdgcn_rcpf(p.d.x), iy = __builtin_amdgcn_rcpf(p.d.y), iz = __builtin_amdgcn_rcpf(p.d.z);
+                        const float widest = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ix), __builtin_fabsf(iy)), __builtin_fabsf(iz));
+                        const float slack = bnc != 0u ? a.cull_slack * widest : RT_INF;
+                        d1 = cull_dist(d1, p.o, ix, iy, iz, slack, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                        d2 = cull_dist(d2, p.o, ix, iy, iz, slack, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                    }
                     // Diagnostic builds only (tools/pad_sensitivity.sh): N independent vector or scalar no-ops per inner-node
                     // step, to measure what one more instruction in this loop costs.
 #ifdef PT_PAD_VNOP

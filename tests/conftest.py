@@ -61,3 +61,33 @@ def rrmse(a: np.ndarray, b: np.ndarray) -> float:
     a = a[..., :3].astype(np.float64)
     b = b[..., :3].astype(np.float64)
     return float(np.sqrt(((a - b) ** 2).sum() / (b**2).sum()))
+
+
+def render_both_ways(pkg, ctx, cam, params, want, cnt_o, start=None, nan_ok=False, what=""):
+    """Renders `params` twice with work counters, as asked and again with RT_FLAG_NO_CULL, and holds both to the oracle's
+    image bit for bit.  The uncut render must also show the oracle's six work counters exactly.  The default render may
+    skip subtrees a bounce ray cannot reach: it must trace the same rays, find the same hits and finish the same paths
+    (counters 2, 3, 5) with no more box tests, triangle tests and node visits (0, 1, 4) than the reference runs.
+    Returns the default render and its counters."""
+    out = None
+    for no_cull in (False, True):
+        p = type(params).from_buffer_copy(params)
+        p.flags |= pkg.RT_FLAG_COUNTERS | (pkg.RT_FLAG_NO_CULL if no_cull else 0)
+        ctx.reset_counters()
+        got = ctx.render(cam, p, None if start is None else start.copy())
+        cnt = ctx.counters()
+        same = bits(got) == bits(want)
+        if nan_ok:
+            same |= np.isnan(got) & np.isnan(want)
+        if not same.all():
+            bad = (~same).any(axis=-1)
+            ys, xs = np.nonzero(bad)
+            raise AssertionError(f"{what} (no_cull={no_cull}): {int(bad.sum())} of {bad.size} pixels differ; first at "
+                                 f"(x={xs[0]}, y={ys[0]}): got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]}")
+        if no_cull:
+            assert np.array_equal(cnt, cnt_o), f"{what}: work counters of the uncut render differ: gpu {cnt} oracle {cnt_o}"
+        else:
+            assert np.array_equal(cnt[[2, 3, 5]], cnt_o[[2, 3, 5]]), f"{what}: rays/hits/paths differ: gpu {cnt} oracle {cnt_o}"
+            assert (cnt[[0, 1, 4]] <= cnt_o[[0, 1, 4]]).all(), f"{what}: more work than the reference: gpu {cnt} oracle {cnt_o}"
+            out = (got, cnt)
+    return out

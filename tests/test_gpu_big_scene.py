@@ -12,7 +12,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import ROOT, FIXTURES, bits
+from conftest import ROOT, FIXTURES, bits, render_both_ways
 
 pytestmark = pytest.mark.gpu
 
@@ -53,18 +53,14 @@ def test_big_primary_hits_full_size(pkg, oracle, big_scene, big_ctx):
 
 @pytest.mark.parametrize("flags_name", ["paths", "paths+fix", "wavefront", "megakernel+fix"])
 def test_big_small_image_bit_exact(pkg, oracle, big_scene, big_ctx, flags_name):
-    flags = pkg.RT_FLAG_COUNTERS
+    flags = 0
     flags |= pkg.RT_FLAG_FIX_INVDIR if "fix" in flags_name else 0
     flags |= pkg.RT_FLAG_WAVEFRONT if "wavefront" in flags_name else 0
     flags |= pkg.RT_FLAG_MEGAKERNEL if "megakernel" in flags_name else 0
     cam = pkg.make_camera(pitch=0.05, yaw=0.1, **CAM)
     p = pkg.make_params(480, 270, frames=3, flags=flags)
-    big_ctx.reset_counters()
-    got = big_ctx.render(cam, p)
-    cnt = big_ctx.counters()
     want, cnt_o = oracle.render(big_scene, cam, p)
-    assert np.array_equal(bits(got), bits(want)), f"{int((bits(got) != bits(want)).any(axis=-1).sum())} pixels differ"
-    assert np.array_equal(cnt, cnt_o)
+    render_both_ways(pkg, big_ctx, cam, p, want, cnt_o, what=flags_name)
 
 
 @pytest.mark.parametrize("fix", [False, True])

@@ -10,7 +10,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import FIXTURES, ROOT, bits
+from conftest import FIXTURES, ROOT, bits, render_both_ways
 
 pytestmark = pytest.mark.gpu
 
@@ -90,13 +90,9 @@ def test_device_build_structure_and_render_parity(pkg, oracle, name):
     ids_o, t_o = oracle.primary_hits(built, cam, 640, 360)
     assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o))
     for flags in (0, pkg.RT_FLAG_FIX_INVDIR, pkg.RT_FLAG_WAVEFRONT, pkg.RT_FLAG_MEGAKERNEL):
-        p = pkg.make_params(480, 270, frames=2, flags=flags | pkg.RT_FLAG_COUNTERS)
-        ctx.reset_counters()
-        got = ctx.render(cam, p)
-        cnt = ctx.counters()
+        p = pkg.make_params(480, 270, frames=2, flags=flags)
         want, cnt_o = oracle.render(built, cam, p)
-        assert np.array_equal(bits(got), bits(want)), f"flags {flags}: {int((bits(got) != bits(want)).any(axis=-1).sum())} pixels differ"
-        assert np.array_equal(cnt, cnt_o)
+        render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"flags {p.flags}")
     assert np.array_equal(bits(ctx.get_normals()), bits(oracle.normals(built)))
     ctx.close()
 
@@ -245,12 +241,9 @@ def test_rebuild_from_device_vertices(pkg, oracle):
         d_v.free()                                                         # the context keeps its own copy
         _validate_tree(built, v2, f)
         assert np.array_equal(built.colours, col[built.tri_src])
-        p = pkg.make_params(480, 270, frames=2, flags=pkg.RT_FLAG_COUNTERS)
-        ctx.reset_counters()
-        got = ctx.render(cam, p)
-        cnt = ctx.counters()
+        p = pkg.make_params(480, 270, frames=2, flags=0)
         want, cnt_o = oracle.render(built, cam, p)
-        assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+        render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"flags {p.flags}")
         assert np.array_equal(bits(ctx.get_normals()), bits(oracle.normals(built)))
         print(f"\n[gpu build] rebuild {step}: {built.num_nodes} nodes, {ms:.2f} ms", flush=True)
     fresh_ctx = pkg.RenderContext(0)
@@ -295,12 +288,9 @@ def test_refit_keeps_topology_and_matches_oracle(pkg, oracle):
         ids_o, t_o = oracle.primary_hits(refit, cam, 640, 360)
         assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o))
         for flags in (0, pkg.RT_FLAG_FIX_INVDIR):
-            p = pkg.make_params(480, 270, frames=2, flags=flags | pkg.RT_FLAG_COUNTERS)
-            ctx.reset_counters()
-            got = ctx.render(cam, p)
-            cnt = ctx.counters()
+            p = pkg.make_params(480, 270, frames=2, flags=flags)
             want, cnt_o = oracle.render(refit, cam, p)
-            assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+            render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"flags {p.flags}")
         assert np.array_equal(bits(ctx.get_normals()), bits(oracle.normals(refit)))
     d_v = pkg.DeviceBuffer.from_array(v2)
     rebuilt, _ = ctx.rebuild_scene_device(d_v.ptr, download=True)
@@ -326,12 +316,9 @@ def test_more_than_2_pow_24_nodes(pkg, oracle):
     assert built.num_nodes > (1 << 24) and built.links is not None
     _validate_tree(built, v, f)
     cam = pkg.make_camera(pos=(0.0, 0.0, -34.0))
-    p = pkg.make_params(320, 180, frames=2, flags=pkg.RT_FLAG_COUNTERS)
-    ctx.reset_counters()
-    got = ctx.render(cam, p)
-    cnt = ctx.counters()
+    p = pkg.make_params(320, 180, frames=2, flags=0)
     want, cnt_o = oracle.render(built, cam, p)
-    assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+    render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"flags {p.flags}")
     ids, t = ctx.primary_hits(cam, 320, 180)
     ctx.close()
     # the same scene through rt_upload_scene: accepted with links, refused without
@@ -374,12 +361,9 @@ def test_device_build_degenerate_inputs(pkg, oracle):
         built, _ = ctx.build_scene_device(v, f, col)
         max_leaf = _validate_tree(built, v, f)
         assert max_leaf >= 1000                                                   # the identical triangles share a leaf
-        p = pkg.make_params(320, 180, frames=2, flags=pkg.RT_FLAG_COUNTERS)
-        ctx.reset_counters()
-        got = ctx.render(cam, p)
-        cnt = ctx.counters()
+        p = pkg.make_params(320, 180, frames=2, flags=0)
         want, cnt_o = oracle.render(built, cam, p)
-        assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+        render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"flags {p.flags}")
         trees[variant] = _canonical(built)
         ctx.close()
     assert np.array_equal(trees["default"][0], trees["level loop only"][0])
@@ -431,11 +415,8 @@ def test_device_build_big_scene_and_animation(pkg, oracle):
         wall = time.time() - t0
         print(f"\n[gpu build] step {step} ({('build', 'rebuild', 'refit')[step]}): {built.num_tris} triangles -> {built.num_nodes} nodes, device build {ms:.1f} ms "
               f"(call incl. upload + download of the tree {wall:.1f} s)", flush=True)
-        p = pkg.make_params(320, 180, frames=2, flags=pkg.RT_FLAG_COUNTERS)
-        ctx.reset_counters()
-        got = ctx.render(cam, p)
-        cnt = ctx.counters()
+        p = pkg.make_params(320, 180, frames=2, flags=0)
         want, cnt_o = oracle.render(built, cam, p)
-        assert np.array_equal(bits(got), bits(want)) and np.array_equal(cnt, cnt_o)
+        render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"flags {p.flags}")
         v = v + rng.normal(0.0, 0.01, v.shape).astype(np.float32)     # animate: perturb every vertex, rebuild
     ctx.close()

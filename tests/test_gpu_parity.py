@@ -9,7 +9,7 @@ be held to it.
 import numpy as np
 import pytest
 
-from conftest import bits, rrmse
+from conftest import bits, render_both_ways, rrmse
 
 pytestmark = pytest.mark.gpu
 
@@ -80,17 +80,14 @@ def test_frame0_full_size(pkg, oracle, gpu_ctx, scenes, name, flags_name):
     """BASELINE configs[0]/[1]: 1920x1080, 1 spp, 100 bounces, Russian roulette, bug-compatible."""
     scene = scenes(name)
     cam = pkg.make_camera(**CAMERAS[name])
-    flags = pkg.RT_FLAG_COUNTERS | _pipeline_flags(pkg, flags_name)
-    params = pkg.make_params(1920, 1080, flags=flags)
+    params = pkg.make_params(1920, 1080, flags=_pipeline_flags(pkg, flags_name))
     gpu_ctx.upload_scene(scene)
-    gpu_ctx.reset_counters()
-    got = gpu_ctx.render(cam, params)
-    cnt = gpu_ctx.counters()
     want, cnt_o = oracle.render(scene, cam, params)
+    got, cnt = render_both_ways(pkg, gpu_ctx, cam, params, want, cnt_o, what=f"{name} {flags_name}")
     assert rrmse(got, want) <= RRMSE_TOL
-    _assert_image_equal(got, want, f"{name} {flags_name}")
-    assert np.array_equal(cnt, cnt_o), f"work counters differ: gpu {cnt} oracle {cnt_o}"
     assert np.all(got[..., 3] == 2.0)
+    if flags_name == "paths" and name == "dragon80k":   # the cull is at work: a third fewer box tests
+        assert cnt[0] < 0.75 * cnt_o[0]
 
 
 @pytest.mark.parametrize("variant", [
@@ -130,17 +127,13 @@ def test_variants_small(pkg, oracle, gpu_ctx, scenes, name, size, variant):
         flags |= pkg.RT_FLAG_SUM
     scene = scenes(name)
     cam = pkg.make_camera(pitch=0.1, yaw=-0.15, **CAMERAS[name])
-    params = pkg.make_params(size[0], size[1], flags=flags | pkg.RT_FLAG_COUNTERS, **variant)
+    params = pkg.make_params(size[0], size[1], flags=flags, **variant)
     gpu_ctx.upload_scene(scene)
-    gpu_ctx.reset_counters()
     start = None
     if params.frame_base != 0:
         start = np.random.RandomState(3).uniform(0, 1, (size[1], size[0], 4)).astype(np.float32)
-    got = gpu_ctx.render(cam, params, None if start is None else start.copy())
-    cnt = gpu_ctx.counters()
     want, cnt_o = oracle.render(scene, cam, params, None if start is None else start.copy())
-    _assert_image_equal(got, want, f"{name} {variant} {fl}")
-    assert np.array_equal(cnt, cnt_o), f"work counters differ: gpu {cnt} oracle {cnt_o}"
+    render_both_ways(pkg, gpu_ctx, cam, params, want, cnt_o, start=start, what=f"{name} {variant} {fl}")
 
 
 def test_pitched_camera_sees_quads(pkg, oracle, gpu_ctx, scenes):
@@ -179,7 +172,7 @@ def test_gpu_against_committed_golden_vectors(pkg, gpu_ctx, scenes, name):
     assert np.array_equal(ids, g["ids"]) and np.array_equal(bits(t), bits(g["t"]))
     for frames, extra, key_img, key_cnt in ((3, 0, "img", "counters"), (2, pkg.RT_FLAG_FIX_INVDIR, "img_fix", "counters_fix")):
         gpu_ctx.reset_counters()
-        img = gpu_ctx.render(cam, pkg.make_params(w, h, frames=frames, flags=extra | pkg.RT_FLAG_COUNTERS))
+        img = gpu_ctx.render(cam, pkg.make_params(w, h, frames=frames, flags=extra | pkg.RT_FLAG_COUNTERS | pkg.RT_FLAG_NO_CULL))
         assert np.array_equal(bits(img), bits(g[key_img]))
         assert np.array_equal(gpu_ctx.counters(), g[key_cnt])
         plain = gpu_ctx.render(cam, pkg.make_params(w, h, frames=frames, flags=extra))   # the non-counting kernels
@@ -458,15 +451,11 @@ def test_config0_teapot_primary_plus_one_bounce(pkg, oracle, gpu_ctx, scenes):
     """BASELINE configs[0]: teapot, 1920x1080, 1 spp, primary + 1 diffuse bounce (ray_bounces = 2)."""
     scene = scenes("teapot")
     cam = pkg.make_camera()
-    p = pkg.make_params(1920, 1080, ray_bounces=2, flags=pkg.RT_FLAG_COUNTERS)
+    p = pkg.make_params(1920, 1080, ray_bounces=2)
     gpu_ctx.upload_scene(scene)
-    gpu_ctx.reset_counters()
-    got = gpu_ctx.render(cam, p)
-    cnt = gpu_ctx.counters()
     want, cnt_o = oracle.render(scene, cam, p)
+    got, _ = render_both_ways(pkg, gpu_ctx, cam, p, want, cnt_o, what="teapot 2 bounces")
     assert rrmse(got, want) <= RRMSE_TOL
-    _assert_image_equal(got, want, "teapot 2 bounces")
-    assert np.array_equal(cnt, cnt_o)
 
 
 def test_config2_4k_progressive_and_sample_partition(pkg, oracle, gpu_ctx, scenes):
@@ -529,16 +518,10 @@ def test_edge_scenes(pkg, oracle, gpu_ctx, case, pipeline):
                          dtype=np.float32)
         scene = _tiny_scene(pkg, [big], nodes)
     cam = pkg.make_camera(pos=(0.0, 0.0, -2.0))
-    flags = pkg.RT_FLAG_COUNTERS | _pipeline_flags(pkg, pipeline)
-    p = pkg.make_params(128, 96, frames=2, flags=flags)
+    p = pkg.make_params(128, 96, frames=2, flags=_pipeline_flags(pkg, pipeline))
     gpu_ctx.upload_scene(scene)
-    gpu_ctx.reset_counters()
-    got = gpu_ctx.render(cam, p)
-    cnt = gpu_ctx.counters()
     want, cnt_o = oracle.render(scene, cam, p)
-    same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
-    assert same.all(), f"{int((~same).any(axis=-1).sum())} pixels differ"
-    assert np.array_equal(cnt, cnt_o)
+    render_both_ways(pkg, gpu_ctx, cam, p, want, cnt_o, nan_ok=True, what=f"{case} {pipeline}")
     ids, t = gpu_ctx.primary_hits(cam, 128, 96)
     ids_o, t_o = oracle.primary_hits(scene, cam, 128, 96)
     assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o))
