@@ -1249,9 +1249,11 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int 
                 m2 = m2 > o2 ? m2 : o2;
             }
         }
+        // the maxima only grow, so a (possibly stale) plain read that already shows a value as large makes the atomic
+        // unnecessary: after the first few waves almost none is issued
         if ((threadIdx.x & 63) == 0) {
-            atomicMax(&edge_max[0], m1);
-            atomicMax(&edge_max[1], m2);
+            if (m1 > __hip_atomic_load(&edge_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&edge_max[0], m1);
+            if (m2 > __hip_atomic_load(&edge_max[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&edge_max[1], m2);
         }
     }
     const rt_vec3 nrm = rt_normalize(rt_cross(rt_sub(a, b), rt_sub(a, c)));

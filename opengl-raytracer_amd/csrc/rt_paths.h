@@ -14,12 +14,16 @@
 //   traverse  ordered BVH traversal; every iteration runs ONE kind of step (inner-node visit or triangle test),
 //             chosen by a weighted vote of the lanes, until too few lanes are still traversing.
 //
-// No single unit binds the kernel.  Measured on dragon80k: the vector ALUs issue ~0.3 instructions per cycle and SIMD (of
-// ~0.4 sustainable), the vector-memory address unit is occupied 93 % of the time, waves spend 26 % of their cycles issuing
-// and 15 % in s_waitcnt; yet removing 7 % of the vector instructions, adding 16 no-ops per step, staging no records in
-// LDS (+78 % memory requests) or halving the resident waves each moves the time by only 0-18 %.  A wave instruction
-// costs the same whatever its EXEC mask, so what pays is fewer loop iterations (more lanes served per iteration) and the
-// hardware maximum of 8 waves per SIMD (64 VGPRs).
+// Bounce rays are traversed the reference's way -- slab tests with the primary ray's stale 1/dir, so the walk follows the
+// primary ray's line -- but a child whose box the ray's TRUE line misses by more than the scene's pad is dropped: no
+// triangle in it can report a hit, so nothing changes except a third of the node visits (see cull_dist below).
+//
+// No single unit binds the kernel.  Measured on dragon80k: the vector ALUs issue ~0.34 instructions per cycle and SIMD (of
+// ~0.4-0.5 sustainable), the vector-memory address unit is occupied 76 % of the time, waves spend 32 % of their cycles
+// issuing and 36 % waiting for an instruction's operands; before the cull, removing 7 % of the vector instructions, adding
+// 16 no-ops per step, staging no records in LDS (+78 % memory requests) or halving the resident waves each moved the time
+// by only 0-18 %.  A wave instruction costs the same whatever its EXEC mask, so what pays is fewer loop iterations (more
+// lanes served per iteration, fewer nodes visited) and the hardware maximum of 8 waves per SIMD (64 VGPRs).
 //
 // Memory placement (LDS is 160 KiB per CU, 80 KiB per workgroup):
 //   traversal stacks   8 (ref, dist) entries per lane, [entry][thread] so 8-byte accesses never conflict: 64 KiB;
