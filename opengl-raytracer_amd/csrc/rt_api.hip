@@ -84,6 +84,12 @@ struct BuiltData {
     bool parents_valid = false;  // nparent filled (first refit after a build)
 };
 
+// the path kernel's cull pad of a scene, see cull_pad_of
+struct CullPad {
+    float slack = -1.0f;   // < 0: never cull; else 2 * pad (reach_slope == 0) or 2 * pad_near
+    float slope = 0.0f;    // 2 * reach_slope
+};
+
 struct rt_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -150,10 +156,11 @@ struct rt_context {
 
     // scheduling parameters of the path kernel; the RT_TUNE_* environment variables (read once, at rt_create) override
     // the defaults for tuning runs
-    // Cull slack of the current scene (see cull_slack_of): twice the pad by which the path kernel widens a child box
-    // before it skips the subtree of a bounce ray that passes it at a distance; < 0: this scene is traversed uncut.
-    float cull_slack = -1.0f;
-    float tune_cull_slack = -2.0f;  // RT_TUNE_CULL_SLACK: >= -1 overrides the scene's value (diagnostics)
+    // Cull pad of the current scene (see cull_pad_of): the pad by which the path kernel widens a child box before it skips
+    // the subtree of a bounce ray that passes it at a distance; slack < 0: this scene is traversed uncut.
+    CullPad cull;
+    float tune_cull_slack = -2.0f;  // RT_TUNE_CULL_SLACK: >= -1 overrides the scene's value with a constant one (diagnostics)
+    int tune_cull_reach = -1;       // RT_TUNE_CULL_REACH: 0 / 1 forces the constant / the reach-dependent pad
     int tune_min_trav = PT_MIN_TRAV, tune_min_service = PT_MIN_SERVICE, tune_w_inner = PT_W_INNER, tune_w_leaf = PT_W_LEAF;
     int tune_cache = -1;  // >= 0: stage at most this many records in LDS
     // workgroups per CU of a launch that renders a single frame: with one, the launches of two consecutive frames are
@@ -191,12 +198,25 @@ static thread_local std::string g_create_error;
 //   approximate reciprocal, a product) is off by at most 4u D per plane.
 // pad = 4 fp + 4 E m2 + u m2 + 8u D: the floating-point part carries a safety factor of 4.  The first-order bounds
 // need the relative error of det to be small, 6.5 u m1 / E << 1: scenes with m1 >= 2 (or a NaN anywhere) are not culled.
-static float cull_slack_of(double D, double m1, double m2) {
+//
+// |s| <= D is the worst case.  For the triangles inside ONE box |s| and T are at most the box's reach from the origin (the
+// largest distance to any of its points), so the same bound with D replaced by the reach R gives a pad that grows with
+// distance: pad(R) = reach_slope * R + pad_near.  The kernel evaluates it (with the L1 reach, which is never smaller) when
+// reach_slope > 0; that costs 12 more vector instructions per step and pays where D is large against the triangles.
+static CullPad cull_pad_of(double D, double m1, double m2, int reach_mode /* 0 never, 1 always, -1 by rule */) {
     const double u = 1.0 / 16777216.0, E = (double)RT_EPS;
-    if (!(D >= 0.0) || !(m1 < 2.0) || !(m2 < 1e18) || !(D < 1e18)) return -1.0f;
-    const double fp = (u / E) * m1 * (29.0 * D + 26.5 * m2) + 2.0 * u * (D + 4.1 * m2);
-    const double pad = 4.0 * fp + 4.0 * E * m2 + u * m2 + 8.0 * u * D;
-    return (float)(2.0 * pad * 1.001);
+    CullPad cp;
+    if (!(D >= 0.0) || !(m1 < 2.0) || !(m2 < 1e18) || !(D < 1e18)) return cp;
+    const double slope = 4.0 * ((u / E) * m1 * 29.0 + 2.0 * u) + 8.0 * u;
+    const double near = 4.0 * ((u / E) * m1 * 26.5 * m2 + 2.0 * u * 4.1 * m2) + 4.0 * E * m2 + u * m2;
+    const double pad = slope * D + near;   // the constant pad: every reach is at most D
+    // by rule: where the constant pad exceeds the longest triangle edge, i.e. the scene is large against its triangles
+    // (measured: 9.27 M-triangle grid, pad 1.3 against edges <= 0.46: 1.21 -> 0.91 ms per frame with the reach-dependent
+    // pad; dragon80k and teapot, pad 0.09 and 0.2 of the longest edge: 5 % slower with it)
+    const bool reach = reach_mode < 0 ? pad > m2 : reach_mode > 0;
+    cp.slack = (float)(2.0 * (reach ? near : pad) * 1.001);
+    cp.slope = reach ? (float)(2.0 * slope * 1.001) : 0.0f;
+    return cp;
 }
 
 static int fail(rt_context* ctx, int code, const char* fmt, ...) {
@@ -465,7 +485,8 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
     a.min_trav = c->tune_min_trav;
     a.min_service = c->tune_min_service;
-    a.cull_slack = (p->flags & RT_FLAG_NO_CULL) ? -1.0f : (c->tune_cull_slack >= -1.0f ? c->tune_cull_slack : c->cull_slack);
+    a.cull_slack = (p->flags & RT_FLAG_NO_CULL) ? -1.0f : (c->tune_cull_slack >= -1.0f ? c->tune_cull_slack : c->cull.slack);
+    a.cull_slope = c->tune_cull_slack >= -1.0f ? 0.0f : c->cull.slope;
     a.w_inner = c->tune_w_inner;
     a.w_leaf = c->tune_w_leaf;
     a.chunk = nframes == 1 ? (uint32_t)c->tune_frame_chunk : 1u;
@@ -661,6 +682,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_MIN_SERVICE")) c->tune_min_service = atoi(e);
     if (const char* e = getenv("RT_TUNE_CACHE")) c->tune_cache = atoi(e);
     if (const char* e = getenv("RT_TUNE_CULL_SLACK")) c->tune_cull_slack = (float)atof(e);  // -1: never cull
+    if (const char* e = getenv("RT_TUNE_CULL_REACH")) c->tune_cull_reach = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_BLOCKS")) c->tune_frame_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_CHUNK")) c->tune_frame_chunk = atoi(e);
     // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
@@ -833,7 +855,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     tris.reserve((size_t)T * 16);
     int root_ref = 0;
     auto as_f = [](int v) { return rt_u2f((uint32_t)v); };
-    // For the path kernel's cull test (cull_slack_of): the largest edge product and edge of any triangle, and whether
+    // For the path kernel's cull test (cull_pad_of): the largest edge product and edge of any triangle, and whether
     // every box lies inside its parent's and every triangle inside its leaf's.  The reference's builder guarantees the
     // latter (bvh.cpp grows a box from its triangles); a caller's own tree that does not, or one with a NaN or infinite
     // vertex, is traversed uncut.
@@ -934,7 +956,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     {
         double diag2 = 0.0;
         for (int k = 0; k < 3; k++) diag2 += ((double)s->nodes[4 + k] - s->nodes[k]) * ((double)s->nodes[4 + k] - s->nodes[k]);
-        c->cull_slack = nested ? cull_slack_of(std::sqrt(diag2), edge_prod_max, edge_max) : -1.0f;
+        c->cull = nested ? cull_pad_of(std::sqrt(diag2), edge_prod_max, edge_max, c->tune_cull_reach) : CullPad();
     }
     c->has_scene = true;
     // a deeper tree may need a larger spill area: force re-allocation on the next render
@@ -942,13 +964,13 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     return RT_OK;
 }
 
-// Cull slack of a device-built tree: its boxes are exact unions of what is below them, the triangle emit kernel has
+// Cull pad of a device-built tree: its boxes are exact unions of what is below them, the triangle emit kernel has
 // reduced the edge maxima (a NaN among them reads back as a NaN).
-static float built_cull_slack(float4 rlo, float4 rhi, const float edge_max[2]) {
+static CullPad built_cull_pad(float4 rlo, float4 rhi, const float edge_max[2], int reach_mode) {
     const double dx = (double)rhi.x - rlo.x, dy = (double)rhi.y - rlo.y, dz = (double)rhi.z - rlo.z;
-    if (!std::isfinite(edge_max[0]) || !std::isfinite(edge_max[1])) return -1.0f;
+    if (!std::isfinite(edge_max[0]) || !std::isfinite(edge_max[1])) return CullPad();
     // the kernel's lengths are fp32: a relative 1e-6 covers their rounding
-    return cull_slack_of(std::sqrt(dx * dx + dy * dy + dz * dz), (double)edge_max[0] * 1.000001, (double)edge_max[1] * 1.000001);
+    return cull_pad_of(std::sqrt(dx * dx + dy * dy + dz * dz), (double)edge_max[0] * 1.000001, (double)edge_max[1] * 1.000001, reach_mode);
 }
 
 // ---- GPU BVH build (rt_build.h) ---------------------------------------------------------------------------
@@ -1112,7 +1134,7 @@ static int build_core(rt_context* c) {
     c->sc.shade = c->d_shade;
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
-    c->cull_slack = built_cull_slack(rlo, rhi, edge_max);
+    c->cull = built_cull_pad(rlo, rhi, edge_max, c->tune_cull_reach);
     c->sc.root_ref = num_nodes == 1 ? ~0 : 0;  // a single leaf starts at triangle 0; otherwise the root owns record 0
     c->sc.num_tris = nf;
     c->num_tris = nf;
@@ -1201,7 +1223,7 @@ int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
     (void)hipEventElapsedTime(&c->last_build_ms, c->build_ev0, c->build_ev1);
     bd.ref_valid = false;
     c->phits_valid = false;
-    c->cull_slack = built_cull_slack(rlo, rhi, edge_max);
+    c->cull = built_cull_pad(rlo, rhi, edge_max, c->tune_cull_reach);
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
     return RT_OK;

@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(BB_BLOCK) void k_build_emit_tris(BuildState s, int 
     q[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     // edge_max[0] = max |e1| * |e2|, edge_max[1] = max(|e1|, |e2|) over all triangles, as float bits: non-negative floats
     // order like their bit patterns, and a NaN (above every number) marks a scene with a NaN vertex.  The path kernel's
-    // cull pad is derived from the two (cull_slack_of in rt_api.hip).
+    // cull pad is derived from the two (cull_pad_of in rt_api.hip).
     {
         const float l1 = rt_sqrt(rt_dot(rt_sub(b, a), rt_sub(b, a))), l2 = rt_sqrt(rt_dot(rt_sub(c, a), rt_sub(c, a)));
         uint32_t m1 = rt_f2u(l1 * l2) & 0x7fffffffu, m2 = rt_f2u(l1) & 0x7fffffffu, m3 = rt_f2u(l2) & 0x7fffffffu;

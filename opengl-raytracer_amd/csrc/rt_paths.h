@@ -82,7 +82,8 @@ struct PathsArgs {
     int min_trav, min_service;      // phase-switch thresholds (lanes)
     int w_inner, w_leaf;            // an inner step runs when w_inner * (lanes at inner nodes) >= w_leaf * (lanes at leaves)
     uint32_t chunk;                 // consecutive grabs of a workgroup take `chunk` consecutive items (1: every grab its own round)
-    float cull_slack;               // < 0: off; else 2 * (pad of every box) for the true-direction cull of the inner-node step
+    float cull_slack, cull_slope;   // true-direction cull of the inner-node step: slack < 0 off; else a box is widened by the pad
+                                    // (cull_slack + cull_slope * reach of the box from the ray origin) / 2
     float2* hits;                   // [pixels] closest hit of every pixel's primary ray, (t, id bits): written in PM_PRIMARY, read in PM_REUSE
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
@@ -211,6 +212,12 @@ __device__ __forceinline__ float cull_dist(float d, rt_vec3 o, float ix, float i
     const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
     const float hi = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
     return hi + slack < lo ? RT_INF : d;
+}
+
+// An upper bound (L1 norm) of the distance from o to the farthest point of a box.
+__device__ __forceinline__ float box_reach(rt_vec3 o, float nx, float ny, float nz, float xx, float xy, float xz) {
+    return (__builtin_fmaxf(__builtin_fabsf(nx - o.x), __builtin_fabsf(xx - o.x)) + __builtin_fmaxf(__builtin_fabsf(ny - o.y), __builtin_fabsf(xy - o.y))) +
+           __builtin_fmaxf(__builtin_fabsf(nz - o.z), __builtin_fabsf(xz - o.z));
 }
 
 template <bool COUNT, bool FIX, int PMODE>
@@ -475,8 +482,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                         const float ix = __builtin_amdgcn_rcpf(p.d.x), iy = __builtin_amdgcn_rcpf(p.d.y), iz = __builtin_amdgcn_rcpf(p.d.z);
                         const float widest = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ix), __builtin_fabsf(iy)), __builtin_fabsf(iz));
                         const float slack = bnc != 0u ? a.cull_slack * widest : RT_INF;
-                        d1 = cull_dist(d1, p.o, ix, iy, iz, slack, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-                        d2 = cull_dist(d2, p.o, ix, iy, iz, slack, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                        float s1 = slack, s2 = slack;
+                        if (a.cull_slope > 0.0f) {  // large scenes: the pad grows with the box's reach from the origin
+                            const float per_reach = a.cull_slope * widest;
+                            s1 = __builtin_fmaf(box_reach(p.o, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y), per_reach, slack);
+                            s2 = __builtin_fmaf(box_reach(p.o, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w), per_reach, slack);
+                        }
+                        d1 = cull_dist(d1, p.o, ix, iy, iz, s1, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                        d2 = cull_dist(d2, p.o, ix, iy, iz, s2, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
                     }
                     // Diagnostic builds only (tools/pad_sensitivity.sh): N independent vector or scalar no-ops per inner-node
                     // step, to measure what one more instruction in this loop costs.

@@ -124,3 +124,23 @@ def test_cull_on_device_built_and_refitted_trees(pkg, oracle):
     same = (bits(got) == bits(want)) | (np.isnan(got) & np.isnan(want))
     assert same.all() and np.array_equal(ctx.counters(), cnt_o)
     ctx.close()
+
+
+@pytest.mark.parametrize("reach", ["0", "1"])
+def test_cull_with_either_pad_rule(pkg, oracle, scenes, reach):
+    """The pad is either one constant per scene or grows with a box's reach from the ray origin; the library picks by the
+    scene's size against its triangles.  Both forced here (RT_TUNE_CULL_REACH is read when a context is created)."""
+    os.environ["RT_TUNE_CULL_REACH"] = reach
+    try:
+        ctx = pkg.RenderContext(0)
+    finally:
+        del os.environ["RT_TUNE_CULL_REACH"]
+    for name, pos, yaw in (("dragon80k", (0.0, 0.0, -5.5), 0.0), ("dragon80k", (0.2, 0.4, -1.0), 0.5), ("teapot", (0.0, 0.0, -2.0), -0.2)):
+        scene = scenes(name)
+        ctx.upload_scene(scene)
+        cam = pkg.make_camera(pos=pos, yaw=yaw)
+        p = pkg.make_params(400, 240, frames=2)
+        want, cnt_o = oracle.render(scene, cam, p)
+        _, cnt = render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"{name} reach={reach}")
+        assert cnt[0] < cnt_o[0]
+    ctx.close()
