@@ -144,3 +144,18 @@ def test_cull_with_either_pad_rule(pkg, oracle, scenes, reach):
         _, cnt = render_both_ways(pkg, ctx, cam, p, want, cnt_o, what=f"{name} reach={reach}")
         assert cnt[0] < cnt_o[0]
     ctx.close()
+
+
+@pytest.mark.parametrize("name,extent", [("dragon80k", 3.0), ("teapot", 2.5)])
+def test_cull_random_cameras(pkg, oracle, gpu_ctx, scenes, name, extent):
+    """Twelve random cameras around and inside each model, four frames each: every image bit-identical to the oracle's with
+    and without the cull."""
+    scene = scenes(name)
+    gpu_ctx.upload_scene(scene)
+    rng = np.random.RandomState(17)
+    for k in range(12):
+        pos = tuple(float(x) for x in rng.uniform(-extent, extent, 3))
+        cam = pkg.make_camera(pos=pos, pitch=float(rng.uniform(-1.2, 1.2)), yaw=float(rng.uniform(-3.1, 3.1)))
+        p = pkg.make_params(240, 136, frames=4)
+        want, cnt_o = oracle.render(scene, cam, p)
+        render_both_ways(pkg, gpu_ctx, cam, p, want, cnt_o, what=f"{name} camera {k} at {pos}")
