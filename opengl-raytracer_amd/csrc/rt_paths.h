@@ -53,8 +53,9 @@
 static_assert(PT_SLOT_SHIFT > 0 && (1 << PT_SLOT_SHIFT) == PT_BLOCK * 8, "PT_BLOCK must be 256, 512 or 1024");
 #define PT_MIN_TRAV 40         // leave the traversal phase when fewer lanes than this still traverse ...
 #define PT_MIN_SERVICE 16       // ... and keep servicing only while at least this many lanes need it
-#define PT_W_INNER 4           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
-#define PT_W_LEAF 7            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise
+#define PT_W_INNER 1           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
+#define PT_W_LEAF 3            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise (a triangle step is the
+                               //              cheaper one and frees its lanes for the next inner steps)
 #define PT_MAX_BATCH 16        // frames per launch.  The end of a launch drains slowly (a few long paths keep their waves
                                // alive, ~0.3 ms on dragon80k); consecutive launches of a call overlap on two streams to hide it
 #define PT_STRIP_W 16          // tile columns per vertical strip of the tile numbering (the last strip may stick out of the image)
