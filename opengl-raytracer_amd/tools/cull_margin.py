@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""How much margin does the pad of the path kernel's subtree cull have?  Renders many random cameras with the cull's
+slack forced to far smaller values than the library derives for the scene (RT_TUNE_CULL_SLACK, read at context creation)
+and counts the pixels that differ from the uncut render (RT_FLAG_NO_CULL) of the same context.  The derived slack is
+printed next to them (it is what `default` runs with).  usage: cull_margin.py [scene] [cameras]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "dragon80k"
+cameras = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+pkg = entry.load_package()
+scene = pkg.load_scene(os.path.join(ROOT, "fixtures", name + ".obj"), colour_seed=1)
+extent = 3.0
+W, H, frames = 480, 270, 8
+for slack in ("default", "0", "1e-7", "1e-6", "1e-5", "1e-4", "1e-3"):
+    if slack == "default":
+        os.environ.pop("RT_TUNE_CULL_SLACK", None)
+    else:
+        os.environ["RT_TUNE_CULL_SLACK"] = slack
+    ctx = pkg.RenderContext(0)
+    ctx.upload_scene(scene)
+    rng = np.random.RandomState(5)
+    bad_pixels = bad_cameras = 0
+    box = box_ref = 0.0
+    for k in range(cameras):
+        pos = tuple(float(x) for x in rng.uniform(-extent, extent, 3))
+        cam = pkg.make_camera(pos=pos, pitch=float(rng.uniform(-1.2, 1.2)), yaw=float(rng.uniform(-3.1, 3.1)))
+        ctx.reset_counters()
+        a = ctx.render(cam, pkg.make_params(W, H, frames=frames, flags=pkg.RT_FLAG_COUNTERS))
+        box += float(ctx.counters()[0])
+        ctx.reset_counters()
+        b = ctx.render(cam, pkg.make_params(W, H, frames=frames, flags=pkg.RT_FLAG_COUNTERS | pkg.RT_FLAG_NO_CULL))
+        box_ref += float(ctx.counters()[0])
+        d = (a.view(np.uint32) != b.view(np.uint32)).any(axis=-1)
+        bad_pixels += int(d.sum())
+        bad_cameras += int(d.any())
+    ctx.close()
+    print(f"{name} slack {slack:8s}: {bad_pixels} differing pixels in {bad_cameras} of {cameras} cameras "
+          f"({W}x{H}, {frames} frames each); box tests {box / box_ref:.3f} of the reference's", flush=True)
