@@ -153,6 +153,22 @@ struct rt_context {
     hipEvent_t lane_done[RT_LANES] = {};   // recorded on lane_stream[k] after its path kernel
     hipEvent_t slot_free[RT_LANES] = {};   // recorded on the context's stream after the accumulate that read slot k
     uint32_t lane_next = 0;
+    // Frames traced ahead of a steady frame-by-frame loop (rt_raytrace_frame called with the same camera and parameters
+    // and consecutive frame counts, as the reference's loop does while the camera stands still): once the pattern has
+    // held for a few calls, a call traces a batch of frames in one launch and the following calls only fold their staged
+    // samples in, while the batch after it is already in flight.  A launch over several frames keeps the lanes busy where
+    // a single-frame launch spends half its time draining.  Results are the same; what is traced ahead and never asked
+    // for (at most one batch and the rest of another when the pattern breaks) is wasted work, so the batches start small.
+    struct Ahead {
+        bool have_last = false;            // cam / params / last_frame describe the previous eligible call
+        DCamera cam;
+        rt_params params;
+        uint32_t last_frame = 0, streak = 0;
+        bool valid = false, next_valid = false;    // staged: frames [base, base + count) in `slot`; [next_base, ...) in next_slot
+        uint32_t base = 0, count = 0, slot = 0, next_base = 0, next_count = 0, next_slot = 0;
+        bool unjoined = false;             // a path launch is in flight that no accumulate on the context's stream waits for
+    } ahead;
+    int tune_ahead = 8;                    // RT_TUNE_AHEAD: most frames per traced-ahead batch; < 2: never trace ahead
 
     // scheduling parameters of the path kernel; the RT_TUNE_* environment variables (read once, at rt_create) override
     // the defaults for tuning runs
@@ -397,12 +413,32 @@ static uint32_t paths_batch(size_t pixels) {
     return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
 }
 
+// Forgets the frames traced ahead.  A launch of theirs may still be running with nothing on the context's stream waiting
+// for it: the context's stream is made to wait, so that whatever the caller does next on it (free or rewrite the scene,
+// reuse a staging slot, synchronise) comes after.
+static void lanes_join(rt_context* c) {
+    if (!c->ahead.unjoined) return;
+    for (int k = 0; k < RT_LANES; k++)
+        if (c->lane_done[k]) (void)hipStreamWaitEvent(c->stream, c->lane_done[k], 0);
+    c->ahead.unjoined = false;
+}
+static void ahead_discard(rt_context* c) {
+    c->ahead.valid = c->ahead.next_valid = false;
+    lanes_join(c);
+}
+static void ahead_reset(rt_context* c) {
+    ahead_discard(c);
+    c->ahead.have_last = false;
+    c->ahead.streak = 0;
+}
+
 static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
     // sized in bytes: a smaller image may render more frames per launch than the one the buffer was made for
     const uint32_t batch = paths_batch(pixels);
     const size_t want_bytes = (size_t)RT_LANES * batch * pixels * sizeof(float4);  // one slot of `batch` frames per lane
     if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries) return RT_OK;
+    ahead_discard(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (want_bytes > c->samples_bytes) {
         dfree(c->d_samples);
@@ -572,6 +608,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     size_t pixels = (size_t)p->width * p->height;
+    ahead_discard(c);  // this launch takes a staging slot of its own
     int rc = ensure_paths_buffers(c, pixels);
     if (rc != RT_OK) return rc;
     // counters and per-kernel timing are read on the context's stream: such calls stay on it
@@ -616,6 +653,95 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     } else {
         for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipEventRecord(c->slot_free[k], c->stream));
     }
+    return RT_OK;
+}
+
+// Path kernel for frames [base, base + count) of a steady loop into staging slot `slot`, on that slot's internal stream.
+static int launch_ahead(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t base, uint32_t count, uint32_t slot) {
+    const BandLayout bl = band_layout(p, false);
+    PathsArgs a;
+    fill_paths_args(c, p, bl, base, 1u, count, a);
+    a.samples = c->d_samples + (size_t)slot * (c->samples_bytes / RT_LANES / sizeof(float4));
+    a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * a.spill_stride : nullptr;
+    hipStream_t pst = c->lane_stream[slot];
+    HIPCHK(c, hipStreamWaitEvent(pst, c->slot_free[slot], 0));  // the slot's last reader has finished
+    launch_k_paths(c, dc, a, false, (p->flags & RT_FLAG_FIX_INVDIR) != 0, PM_TRACE, true, pst);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->lane_done[slot], pst));
+    c->ahead.unjoined = true;
+    return RT_OK;
+}
+
+// rt_raytrace_frame on the default pipeline.  Keeps track of whether the calls form a steady loop (see rt_context::Ahead)
+// and, when they do, serves the frame from samples traced ahead or traces the next batch; otherwise one pipelined
+// single-frame launch.
+static int frame_call(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_count, const float4* prev, float4* out) {
+    rt_context::Ahead& ah = c->ahead;
+    const bool eligible = c->tune_ahead >= 2 && !c->profiling && !(p->flags & (RT_FLAG_COUNTERS | RT_FLAG_REUSE_PRIMARY));
+    if (!eligible) {
+        ahead_reset(c);
+        return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, prev, out, true);
+    }
+    const bool same = ah.have_last && std::memcmp(&ah.cam, &dc, sizeof dc) == 0 && std::memcmp(&ah.params, p, sizeof *p) == 0 &&
+                      frame_count == ah.last_frame + 1u;
+    ah.streak = same ? ah.streak + 1u : 0u;
+    ah.cam = dc;
+    ah.params = *p;
+    ah.last_frame = frame_count;
+    ah.have_last = true;
+    if (!same) ahead_discard(c);
+
+    const size_t pixels = (size_t)p->width * p->height;
+    int rc;
+    if (ah.valid && frame_count == ah.base + ah.count) {  // the current batch is used up: on to the one in flight, if any
+        ah.valid = ah.next_valid;
+        ah.base = ah.next_base;
+        ah.count = ah.next_count;
+        ah.slot = ah.next_slot;
+        ah.next_valid = false;
+    }
+    if (ah.valid && !(frame_count >= ah.base && frame_count < ah.base + ah.count)) ahead_discard(c);
+    // Batch size by how long the loop has been steady: what is traced ahead and never asked for is wasted, and a loop that
+    // has run for 40 frames is likelier to run for 8 more than one that has run for 3.
+    const uint32_t want = ah.streak < 2u ? 1u : ah.streak < 6u ? 2u : ah.streak < 40u ? 4u : (uint32_t)c->tune_ahead;
+    const uint32_t cap = std::min<uint32_t>(paths_batch(pixels), std::min<uint32_t>(want, (uint32_t)c->tune_ahead));
+    if (!ah.valid) {
+        const uint32_t k = cap;
+        if (k < 2u) return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, prev, out, true);
+        if ((rc = ensure_paths_buffers(c, pixels)) != RT_OK) return rc;
+        ah.base = frame_count;
+        ah.count = k;
+        ah.slot = c->lane_next++ % RT_LANES;
+        ah.valid = true;
+        if ((rc = launch_ahead(c, dc, p, ah.base, ah.count, ah.slot)) != RT_OK) {
+            ah.valid = false;
+            return rc;
+        }
+    }
+    const uint32_t j = frame_count - ah.base;
+    // with the last frame of a batch the next batch goes out: a caller that issues its calls without waiting for them has
+    // it in the queue long before the GPU gets there, and the two launches overlap on their streams
+    if (j + 1u == ah.count && !ah.next_valid && cap >= 2u) {
+        ah.next_base = ah.base + ah.count;
+        ah.next_count = cap;
+        ah.next_slot = c->lane_next++ % RT_LANES;
+        if (ah.next_slot == ah.slot) ah.next_slot = (ah.slot + 1u) % RT_LANES;
+        if ((rc = launch_ahead(c, dc, p, ah.next_base, ah.next_count, ah.next_slot)) != RT_OK) return rc;
+        ah.next_valid = true;
+    }
+    // fold frame j of the current batch in, on the context's stream, after the batch's path kernel
+    const BandLayout bl = band_layout(p);
+    PathsArgs a;
+    fill_paths_args(c, p, bl, frame_count, 1u, 1u, a);
+    a.samples = c->d_samples + (size_t)ah.slot * (c->samples_bytes / RT_LANES / sizeof(float4)) + (size_t)j * pixels;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[ah.slot], 0));
+    if (!ah.next_valid) c->ahead.unjoined = false;  // every launch in flight now has a waiter on the context's stream
+    {
+        LaunchTimer lt(c, RT_K_ACCUMULATE);
+        launch_k_accumulate(c, p, bl, a, prev, out);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->slot_free[ah.slot], c->stream));  // moved on with every frame folded in: the last one frees the slot
     return RT_OK;
 }
 
@@ -683,6 +809,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_CACHE")) c->tune_cache = atoi(e);
     if (const char* e = getenv("RT_TUNE_CULL_SLACK")) c->tune_cull_slack = (float)atof(e);  // -1: never cull
     if (const char* e = getenv("RT_TUNE_CULL_REACH")) c->tune_cull_reach = atoi(e);
+    if (const char* e = getenv("RT_TUNE_AHEAD")) c->tune_ahead = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_BLOCKS")) c->tune_frame_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_CHUNK")) c->tune_frame_chunk = atoi(e);
     // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
@@ -746,6 +873,7 @@ int rt_destroy(rt_context* c) {
 
 int rt_set_stream(rt_context* c, void* hip_stream) {
     if (!c) return RT_EINVAL;
+    ahead_reset(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RT_OK;
@@ -760,6 +888,7 @@ int rt_get_stream(rt_context* c, void** out_hip_stream) {
 
 int rt_synchronize(rt_context* c) {
     if (!c) return RT_EINVAL;
+    lanes_join(c);  // frames traced ahead are in flight on the internal streams: "everything issued" includes them
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
@@ -910,6 +1039,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     }
 
     HIPCHK(c, hipSetDevice(c->device));
+    ahead_reset(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     size_t nrec = recs.size() / 16, ntri = tris.size() / 16;
@@ -977,6 +1107,7 @@ static CullPad built_cull_pad(float4 rlo, float4 rhi, const float edge_max[2], i
 // Builds from the topology kept in the context (c->bd) and the vertices in c->bd.d_verts.  All device memory comes from
 // the cached workspace or from output buffers sized for the worst case, so that a rebuild allocates nothing.
 static int build_core(rt_context* c) {
+    ahead_reset(c);  // nothing traced ahead may still read the tree that is about to be rewritten
     BuiltData& bd = c->bd;
     const int nf = bd.nf, max_nodes = 2 * nf;
     const bool v1 = c->build_gen == 1;  // first-generation level loop all the way down (kept as the cross-check)
@@ -1196,6 +1327,7 @@ int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
     if (bd.nf <= 0 || !bd.d_faces || !c->built_nodes || !c->has_scene)
         return fail(c, RT_ENOSCENE, "rt_refit_scene_device needs a scene built by rt_build_scene_device");
     HIPCHK(c, hipSetDevice(c->device));
+    ahead_reset(c);
     hipStream_t st = c->stream;
     const int nf = bd.nf, num_nodes = c->built_nodes;
     const dim3 blk(BB_BLOCK), grid_n((num_nodes + BB_BLOCK - 1) / BB_BLOCK), grid_t((nf + BB_BLOCK - 1) / BB_BLOCK);
@@ -1315,8 +1447,8 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
     if (!d_prev_frame && (sum || frame_count != 0)) return fail(c, RT_EINVAL, "d_prev_frame is NULL for frame %u", frame_count);
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
-    if (!mega && !wavefront)
-        return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, (const float4*)d_prev_frame, (float4*)d_out_frame, true);
+    if (!mega && !wavefront) return frame_call(c, dc, p, frame_count, (const float4*)d_prev_frame, (float4*)d_out_frame);
+    ahead_reset(c);
     if ((rc = ensure_buffers(c, p->width, p->height)) != RT_OK) return rc;
 
     FrameArgs fa;
@@ -1540,6 +1672,7 @@ int rt_reset_counters(rt_context* c) {
 
 int rt_set_profiling(rt_context* c, int enable) {
     if (!c) return RT_EINVAL;
+    ahead_reset(c);
     c->profiling = enable != 0;
     return RT_OK;
 }

@@ -649,3 +649,79 @@ def test_upload_with_integer_links(pkg, oracle, scenes):
     with pytest.raises(RuntimeError):
         ctx.upload_scene(pkg.Scene(nodes, scene.triv0, scene.triv1, scene.triv2, scene.colours))
     ctx.close()
+
+
+def test_steady_frame_loop_traces_ahead_and_stays_exact(pkg, oracle, gpu_ctx, scenes):
+    """A steady frame-by-frame loop (same camera, consecutive frame counts) is served from frames the library traces
+    ahead in batches.  Whatever interrupts the pattern -- a synchronise, a camera move, a jump in the frame count, a batched
+    call, another image size, a new scene -- the accumulated image equals the oracle's running mean bit for bit."""
+    W, H = 320, 180
+    scene = scenes("dragon80k")
+    gpu_ctx.upload_scene(scene)
+    p1 = pkg.make_params(W, H)
+    bufs = [pkg.DeviceBuffer(W * H * 16), pkg.DeviceBuffer(W * H * 16)]
+
+    def loop(cam, first, n, params=p1, b=bufs):
+        for f in range(first, first + n):
+            gpu_ctx.raytrace_frame(cam, params, f, b[(f + 1) & 1].ptr, b[f & 1].ptr)
+        return b[(first + n - 1) & 1]
+
+    def image(buf, w=W, h=H):
+        gpu_ctx.synchronize()
+        return buf.to_array((h, w, 4), np.float32)
+
+    cam = pkg.make_camera(**CAMERAS["dragon80k"])
+    # 1. a long steady loop: batches of 2, 4, 8, 8, ... are traced ahead
+    want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=45))
+    assert np.array_equal(bits(image(loop(cam, 0, 45))), bits(want))
+    # 2. a synchronise in the middle of a batch, then on
+    last = loop(cam, 0, 13)
+    gpu_ctx.synchronize()
+    last = loop(cam, 13, 9)
+    want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=22))
+    assert np.array_equal(bits(image(last)), bits(want))
+    # 3. the camera moves while frames of the old camera are staged: accumulation restarts at frame 0
+    loop(cam, 0, 11)
+    cam2 = pkg.make_camera(yaw=0.15, **CAMERAS["dragon80k"])
+    want, _ = oracle.render(scene, cam2, pkg.make_params(W, H, frames=7))
+    assert np.array_equal(bits(image(loop(cam2, 0, 7))), bits(want))
+    # 4. a batched call in the middle (it takes the staging slots), then the loop goes on
+    last = loop(cam, 0, 10)
+    gpu_ctx.render_device(cam, pkg.make_params(W, H, frames=5, frame_base=10), last.ptr)   # frames 10..14 in place
+    other = bufs[0] if last is bufs[1] else bufs[1]
+    f = 15
+    src, dst = last, other
+    for _ in range(9):                                                                      # frames 15..23
+        gpu_ctx.raytrace_frame(cam, p1, f, src.ptr, dst.ptr)
+        src, dst = dst, src
+        f += 1
+    want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=24))
+    assert np.array_equal(bits(image(src)), bits(want))
+    # 5. two loops of different image sizes interleaved call by call: neither is steady, both stay exact
+    w2, h2 = 200, 120
+    p2 = pkg.make_params(w2, h2)
+    small = [pkg.DeviceBuffer(w2 * h2 * 16), pkg.DeviceBuffer(w2 * h2 * 16)]
+    for f in range(9):
+        gpu_ctx.raytrace_frame(cam, p1, f, bufs[(f + 1) & 1].ptr, bufs[f & 1].ptr)
+        gpu_ctx.raytrace_frame(cam, p2, f, small[(f + 1) & 1].ptr, small[f & 1].ptr)
+    want, _ = oracle.render(scene, cam, pkg.make_params(W, H, frames=9))
+    want2, _ = oracle.render(scene, cam, pkg.make_params(w2, h2, frames=9))
+    assert np.array_equal(bits(image(bufs[0])), bits(want))
+    assert np.array_equal(bits(image(small[0], w2, h2)), bits(want2))
+    # 6. a new scene while frames of the old one are in flight
+    loop(cam, 0, 12)
+    teapot = scenes("teapot")
+    gpu_ctx.upload_scene(teapot)
+    camt = pkg.make_camera(**CAMERAS["teapot"])
+    want, _ = oracle.render(teapot, camt, pkg.make_params(W, H, frames=20))
+    assert np.array_equal(bits(image(loop(camt, 0, 20))), bits(want))
+    # 7. plain sums (RT_FLAG_SUM) and the fixed invDir take the same path
+    ps = pkg.make_params(W, H, flags=pkg.RT_FLAG_SUM | pkg.RT_FLAG_FIX_INVDIR)
+    zero = np.zeros((H, W, 4), dtype=np.float32)
+    sb = [pkg.DeviceBuffer.from_array(zero), pkg.DeviceBuffer.from_array(zero)]
+    last = loop(camt, 0, 18, ps, sb)
+    want, _ = oracle.render(teapot, camt, pkg.make_params(W, H, frames=18, flags=pkg.RT_FLAG_SUM | pkg.RT_FLAG_FIX_INVDIR))
+    got = image(last)
+    assert rrmse(got, want) < 1e-6
+    for b in bufs + small + sb:
+        b.free()
