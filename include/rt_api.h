@@ -146,8 +146,12 @@ int rt_set_stream(rt_context* ctx, void* hip_stream);
 /* The hipStream_t the context currently issues its work on (its own unless rt_set_stream changed it), so that a caller
  * can enqueue its own kernels and copies in order with the library's instead of creating another stream. */
 int rt_get_stream(rt_context* ctx, void** out_hip_stream);
-/* Blocks until all work issued on the context's stream has finished. */
+/* Blocks until all work issued on the context's stream has finished, frames traced ahead included. */
 int rt_synchronize(rt_context* ctx);
+/* Most frames rt_raytrace_frame traces ahead of a steady frame-by-frame loop in one launch (default 8, at most 16;
+ * 0 or 1: never trace ahead -- for callers that move the camera every few frames and want no discarded work).
+ * No counterpart in the reference. */
+int rt_set_frames_ahead(rt_context* ctx, int32_t max_frames);
 
 /* ---- scene ------------------------------------------------------------------------- */
 /* initBuffers (raytrace.cpp:38-57): validates and copies the scene, re-lays it out for the
@@ -193,7 +197,11 @@ int rt_get_built_links(rt_context* ctx, int32_t* links);
  * height, rays_per_pixel, ray_bounces, render_mode, flags; asynchronous.
  * Consecutive calls overlap on the GPU: the traversal of a frame runs on an internal stream and only the
  * step that reads d_prev_frame and writes d_out_frame is ordered on the context's stream, which is all a
- * caller can observe -- work enqueued on that stream after the call sees the finished frame. */
+ * caller can observe -- work enqueued on that stream after the call sees the finished frame.
+ * A steady loop (the same camera and params, frame_count going up by one, the reference's loop while the camera
+ * stands still, main.cpp:183-203) is recognised after two calls: the coming frames are then traced ahead in batches
+ * of up to rt_set_frames_ahead() frames and a call only folds its own frame's samples in.  The pixels are the same;
+ * whatever was traced ahead and is not asked for next is discarded. */
 int rt_raytrace_frame(rt_context* ctx, const rt_camera* cam, const rt_params* params,
                       uint32_t frame_count, const float* d_prev_frame, float* d_out_frame);
 

@@ -116,6 +116,7 @@ HIP_SYMBOLS = [
     "rt_last_error",
     "rt_set_stream",
     "rt_get_stream",
+    "rt_set_frames_ahead",
     "rt_synchronize",
     "rt_upload_scene",
     "rt_get_normals",
@@ -184,6 +185,7 @@ def load_hip() -> C.CDLL:
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_set_stream.argtypes = [vp, vp]
         lib.rt_get_stream.argtypes = [vp, C.POINTER(vp)]
+        lib.rt_set_frames_ahead.argtypes = [vp, C.c_int32]
         lib.rt_synchronize.argtypes = [vp]
         lib.rt_upload_scene.argtypes = [vp, C.POINTER(RtScene)]
         lib.rt_get_normals.argtypes = [vp, c_float_p]
@@ -405,6 +407,10 @@ class RenderContext:
         h = C.c_void_p()
         self._check(self.lib.rt_get_stream(self.ctx, C.byref(h)), "rt_get_stream")
         return h.value or 0
+
+    def set_frames_ahead(self, max_frames: int):
+        """Most frames raytrace_frame traces ahead of a steady frame-by-frame loop per launch (0: never)."""
+        self._check(self.lib.rt_set_frames_ahead(self.ctx, max_frames), "rt_set_frames_ahead")
 
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.ctx), "rt_synchronize")

@@ -815,6 +815,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
     // traverse while some wait for a refill would send the wave back and forth without progress
     auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    c->tune_ahead = clamp(c->tune_ahead, 0, PT_MAX_BATCH);
     c->tune_min_trav = clamp(c->tune_min_trav, 1, 48);
     c->tune_min_service = clamp(c->tune_min_service, 1, 64);
     c->tune_w_inner = clamp(c->tune_w_inner, 1, 64);
@@ -876,6 +877,14 @@ int rt_set_stream(rt_context* c, void* hip_stream) {
     ahead_reset(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+
+int rt_set_frames_ahead(rt_context* c, int32_t max_frames) {
+    if (!c) return RT_EINVAL;
+    if (max_frames < 0 || max_frames > PT_MAX_BATCH) return fail(c, RT_EINVAL, "max_frames must be in [0, %d]", PT_MAX_BATCH);
+    ahead_reset(c);
+    c->tune_ahead = max_frames;
     return RT_OK;
 }
 

@@ -723,5 +723,15 @@ def test_steady_frame_loop_traces_ahead_and_stays_exact(pkg, oracle, gpu_ctx, sc
     want, _ = oracle.render(teapot, camt, pkg.make_params(W, H, frames=18, flags=pkg.RT_FLAG_SUM | pkg.RT_FLAG_FIX_INVDIR))
     got = image(last)
     assert rrmse(got, want) < 1e-6
+    # 8. switched off and on again through the API
+    gpu_ctx.set_frames_ahead(0)
+    want, _ = oracle.render(teapot, camt, pkg.make_params(W, H, frames=9))
+    assert np.array_equal(bits(image(loop(camt, 0, 9))), bits(want))
+    gpu_ctx.set_frames_ahead(16)
+    want, _ = oracle.render(teapot, camt, pkg.make_params(W, H, frames=70))
+    assert np.array_equal(bits(image(loop(camt, 0, 70))), bits(want))
+    gpu_ctx.set_frames_ahead(8)
+    with pytest.raises(RuntimeError):
+        gpu_ctx.set_frames_ahead(17)
     for b in bufs + small + sb:
         b.free()
