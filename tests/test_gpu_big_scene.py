@@ -1,4 +1,4 @@
-"""BASELINE configs[3]: synthetic ~10M-triangle scene (baked instances of the dragon stand-in and the teapot on a
+"""Benchmark configuration 3: synthetic ~10M-triangle scene (baked instances of the dragon stand-in and the teapot on a
 jittered grid, 9.27 M triangles, 15.9 M BVH nodes -- just under the 2^24 limit of the reference's float-encoded
 node ids), incoherent deep traversal out of HBM (the device layout is ~1.6 GB).
 

@@ -77,7 +77,7 @@ def _pipeline_flags(pkg, name):
 @pytest.mark.parametrize("flags_name", ["paths", "wavefront", "megakernel"])
 @pytest.mark.parametrize("name", ["teapot", "dragon80k"])
 def test_frame0_full_size(pkg, oracle, gpu_ctx, scenes, name, flags_name):
-    """BASELINE configs[0]/[1]: 1920x1080, 1 spp, 100 bounces, Russian roulette, bug-compatible."""
+    """Benchmark configurations 0 and 1: 1920x1080, 1 spp, 100 bounces, Russian roulette, bug-compatible."""
     scene = scenes(name)
     cam = pkg.make_camera(**CAMERAS[name])
     params = pkg.make_params(1920, 1080, flags=_pipeline_flags(pkg, flags_name))
@@ -448,7 +448,7 @@ def test_headless_rccl_reduce_single_rank(pkg, oracle, scenes, tmp_path, mode):
 
 
 def test_config0_teapot_primary_plus_one_bounce(pkg, oracle, gpu_ctx, scenes):
-    """BASELINE configs[0]: teapot, 1920x1080, 1 spp, primary + 1 diffuse bounce (ray_bounces = 2)."""
+    """Benchmark configuration 0: teapot, 1920x1080, 1 spp, primary + 1 diffuse bounce (ray_bounces = 2)."""
     scene = scenes("teapot")
     cam = pkg.make_camera()
     p = pkg.make_params(1920, 1080, ray_bounces=2)
@@ -459,7 +459,7 @@ def test_config0_teapot_primary_plus_one_bounce(pkg, oracle, gpu_ctx, scenes):
 
 
 def test_config2_4k_progressive_and_sample_partition(pkg, oracle, gpu_ctx, scenes):
-    """BASELINE configs[2]: dragon stand-in at 3840x2160, progressive accumulation, sample-partitioned.
+    """Benchmark configuration 2: dragon stand-in at 3840x2160, progressive accumulation, sample-partitioned.
     Bit-exact against the oracle for the first two frames at full size; then the full 256 spp through
     size-independent properties: (1) resuming in two halves equals one shot, (2) eight interleaved partial SUMs
     divided by 256 equal the sequential running mean to fp32 rounding (the multi-GPU decomposition)."""
@@ -564,7 +564,7 @@ def test_two_contexts_are_independent(pkg, oracle, scenes):
 @pytest.mark.parametrize("interleaved", [False, True])
 @pytest.mark.parametrize("size,bands", [((333, 217), 3), ((640, 360), 8), ((64, 20), 5), ((200, 1080 // 4), 2)])
 def test_band_partition_union_equals_whole_image(pkg, oracle, gpu_ctx, scenes, size, bands, interleaved):
-    """Image-tile partition (BASELINE configs[4]): each band rendered by its own call, into the rows
+    """Image-tile partition (benchmark configuration 4): each band rendered by its own call, into the rows
     partition.band_rows() names and nowhere else; the union is bit-identical to the whole image and to the oracle."""
     from opengl_raytracer_amd import partition
     scene = scenes("teapot")
