@@ -735,3 +735,62 @@ def test_steady_frame_loop_traces_ahead_and_stays_exact(pkg, oracle, gpu_ctx, sc
         gpu_ctx.set_frames_ahead(17)
     for b in bufs + small + sb:
         b.free()
+
+
+def test_frame_loop_random_operation_sequences(pkg, gpu_ctx, scenes):
+    """Seeded random sequences of frame calls (continuing, repeating or jumping in frame count), camera changes, batched
+    calls, synchronisations and look-ahead settings, run on two contexts: one traces ahead, the other never does.  Their
+    framebuffers must agree bit for bit after every sequence -- the look-ahead may never be observable."""
+    W, H = 160, 96
+    scene = scenes("dragon80k")
+    plain = pkg.RenderContext(0)
+    plain.set_frames_ahead(0)
+    for ctx in (gpu_ctx, plain):
+        ctx.upload_scene(scene)
+    gpu_ctx.set_frames_ahead(8)
+    p1 = pkg.make_params(W, H)
+    cams = [pkg.make_camera(yaw=0.1 * k, **CAMERAS["dragon80k"]) for k in range(3)]
+    for seed in range(6):
+        rng = np.random.RandomState(100 + seed)
+        ops = []
+        frame, cam = 0, 0
+        for _ in range(120):
+            r = rng.uniform()
+            if r < 0.78:
+                ops.append(("frame", cam, frame))
+                frame += 1
+            elif r < 0.84:
+                cam = int(rng.randint(0, 3))
+                frame = 0
+            elif r < 0.88:
+                frame = max(0, frame + int(rng.randint(-3, 6)))          # a jump: repeated or skipped frame counts
+            elif r < 0.92:
+                ops.append(("sync",))
+            elif r < 0.96:
+                n = int(rng.randint(1, 6))
+                ops.append(("batch", cam, frame, n))
+                frame += n
+            else:
+                ops.append(("ahead", int(rng.choice([0, 2, 4, 8, 16]))))
+        results = []
+        for ctx in (gpu_ctx, plain):
+            zero = np.zeros((H, W, 4), dtype=np.float32)
+            bufs = [pkg.DeviceBuffer.from_array(zero), pkg.DeviceBuffer.from_array(zero)]
+            cur = 0                                                        # index of the buffer holding the latest image
+            for op in ops:
+                if op[0] == "frame":
+                    ctx.raytrace_frame(cams[op[1]], p1, op[2], bufs[cur].ptr, bufs[cur ^ 1].ptr)
+                    cur ^= 1
+                elif op[0] == "sync":
+                    ctx.synchronize()
+                elif op[0] == "batch":
+                    ctx.render_device(cams[op[1]], pkg.make_params(W, H, frames=op[3], frame_base=op[2]), bufs[cur].ptr)
+                elif op[0] == "ahead" and ctx is gpu_ctx:
+                    ctx.set_frames_ahead(op[1])
+            ctx.synchronize()
+            results.append(bufs[cur].to_array((H, W, 4), np.float32))
+            for b in bufs:
+                b.free()
+        assert np.array_equal(bits(results[0]), bits(results[1])), f"sequence {seed}"
+    gpu_ctx.set_frames_ahead(8)
+    plain.close()
