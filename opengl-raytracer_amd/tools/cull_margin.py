@@ -15,16 +15,26 @@ import __graft_entry__ as entry  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "dragon80k"
 cameras = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 pkg = entry.load_package()
-scene = pkg.load_scene(os.path.join(ROOT, "fixtures", name + ".obj"), colour_seed=1)
-extent = 3.0
+if name == "grid":   # the 9.27 M-triangle scene, built on the device
+    sys.path.insert(0, os.path.join(ROOT, "opengl-raytracer_amd", "tools"))
+    import gen_scenes
+    fx = os.path.join(ROOT, "fixtures")
+    gv, gf = gen_scenes.grid([os.path.join(fx, "dragon80k.obj")] * 3 + [os.path.join(fx, "teapot.obj")], (6, 5, 5), 8.0, 7)
+    scene, extent = None, 24.0
+else:
+    scene = pkg.load_scene(os.path.join(ROOT, "fixtures", name + ".obj"), colour_seed=1)
+    extent = 3.0
 W, H, frames = 480, 270, 8
-for slack in ("default", "0", "1e-7", "1e-6", "1e-5", "1e-4", "1e-3"):
+for slack in (os.environ.get("SLACKS", "default,0,1e-7,1e-6,1e-5,1e-4,1e-3").split(",")):
     if slack == "default":
         os.environ.pop("RT_TUNE_CULL_SLACK", None)
     else:
         os.environ["RT_TUNE_CULL_SLACK"] = slack
     ctx = pkg.RenderContext(0)
-    ctx.upload_scene(scene)
+    if scene is None:
+        ctx.build_scene_device(gv.astype(np.float32), gf.astype(np.uint32), pkg.make_colours(1, gf.shape[0]), download=False)
+    else:
+        ctx.upload_scene(scene)
     rng = np.random.RandomState(5)
     bad_pixels = bad_cameras = 0
     box = box_ref = 0.0
