@@ -140,6 +140,7 @@ HIP_SYMBOLS = [
 
 _host = None
 _hip = None
+_hip_tune = None
 
 
 def load_host() -> C.CDLL:
@@ -169,12 +170,14 @@ def load_host() -> C.CDLL:
     return _host
 
 
-def load_hip() -> C.CDLL:
-    """Loads librt_hip.so; raises if it has not been built (no fallback exists)."""
-    global _hip
-    if _hip is None:
+def load_hip(tunable: bool = False) -> C.CDLL:
+    """Loads librt_hip.so; raises if it has not been built (no fallback exists).  tunable=True loads librt_hip_tune.so
+    instead: the same sources built with -DRT_TUNABLES, the only build that reads RT_TUNE_* / RT_BUILD_* from the
+    environment (tools and the tests that cross-check a non-default variant; both libraries can be loaded side by side)."""
+    global _hip, _hip_tune
+    if (_hip_tune if tunable else _hip) is None:
         # RT_HIP_LIB lets a developer load an instrumented build of the same library
-        path = os.environ.get("RT_HIP_LIB") or os.path.join(CSRC, "librt_hip.so")
+        path = os.environ.get("RT_HIP_LIB") or os.path.join(CSRC, "librt_hip_tune.so" if tunable else "librt_hip.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (make -C {CSRC})")
         lib = C.CDLL(path)
@@ -211,8 +214,11 @@ def load_hip() -> C.CDLL:
             fn = getattr(lib, name)
             if name not in ("rt_last_error", "rt_version"):
                 fn.restype = C.c_int
-        _hip = lib
-    return _hip
+        if tunable:
+            _hip_tune = lib
+        else:
+            _hip = lib
+    return _hip_tune if tunable else _hip
 
 
 def build_id() -> str:
@@ -378,8 +384,8 @@ def make_params(width=1920, height=1080, rays_per_pixel=1, ray_bounces=100, rend
 class RenderContext:
     """Thin owner of an rt_context; every method goes straight through the C ABI."""
 
-    def __init__(self, device_id: int = 0):
-        self.lib = load_hip()
+    def __init__(self, device_id: int = 0, tunable: bool = False):
+        self.lib = load_hip(tunable)
         self.ctx = C.c_void_p()
         rc = self.lib.rt_create(device_id, C.byref(self.ctx))
         if rc != 0:

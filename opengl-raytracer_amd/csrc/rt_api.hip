@@ -166,12 +166,12 @@ struct rt_context {
         uint32_t last_frame = 0, streak = 0;
         bool valid = false, next_valid = false;    // staged: frames [base, base + count) in `slot`; [next_base, ...) in next_slot
         uint32_t base = 0, count = 0, slot = 0, next_base = 0, next_count = 0, next_slot = 0;
-        bool unjoined = false;             // a path launch is in flight that no accumulate on the context's stream waits for
+        uint32_t unjoined = 0;             // bit k: a path launch may be in flight on internal stream k that nothing on the context's stream waits for
     } ahead;
     int tune_ahead = 8;                    // RT_TUNE_AHEAD: most frames per traced-ahead batch; < 2: never trace ahead
 
-    // scheduling parameters of the path kernel; the RT_TUNE_* environment variables (read once, at rt_create) override
-    // the defaults for tuning runs
+    // scheduling parameters of the path kernel; a tuning build (-DRT_TUNABLES) lets RT_TUNE_* environment variables
+    // override them at rt_create, the shipped library runs with these defaults
     // Cull pad of the current scene (see cull_pad_of): the pad by which the path kernel widens a child box before it skips
     // the subtree of a bounce ray that passes it at a distance; slack < 0: this scene is traversed uncut.
     CullPad cull;
@@ -183,6 +183,7 @@ struct rt_context {
     // resident side by side for their whole duration and each fills the issue slots the other's drain leaves idle
     int tune_frame_blocks = 1;
     int tune_frame_chunk = 1;                  // PathsArgs::chunk of such a launch
+    int tune_packets = 1;                      // 0: primary rays are traced lane by lane like bounce rays (A/B runs)
 
     unsigned long long* d_counters = nullptr;
     unsigned char* scratch_ptr = nullptr;  // this device's copy of the static scratch array (rt_raytrace_frame_noalloc)
@@ -413,21 +414,23 @@ static uint32_t paths_batch(size_t pixels) {
     return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
 }
 
-// Forgets the frames traced ahead.  A launch of theirs may still be running with nothing on the context's stream waiting
-// for it: the context's stream is made to wait, so that whatever the caller does next on it (free or rewrite the scene,
-// reuse a staging slot, synchronise) comes after.
+// Frames traced ahead and then not asked for (the camera moved, the frame count jumped) are only forgotten: their
+// launches run to the end on their internal streams, and whatever follows on such a stream -- the next launch into the
+// same staging slot -- is ordered behind them by the stream itself.  The context's stream does not wait for them, so the
+// first frame after a camera move is held up by the discarded work of ONE internal stream at most (the one its own
+// launch goes to), not by both.  ahead.unjoined remembers that such a launch may still be running with nothing on the
+// context's stream waiting for it: before anything that the caller may follow up with a free or a rewrite of what
+// those launches read or write (scene upload, build, refit, staging reallocation, stream change, synchronise) the
+// context's stream is made to wait (lanes_join).
 static void lanes_join(rt_context* c) {
-    if (!c->ahead.unjoined) return;
     for (int k = 0; k < RT_LANES; k++)
-        if (c->lane_done[k]) (void)hipStreamWaitEvent(c->stream, c->lane_done[k], 0);
-    c->ahead.unjoined = false;
+        if ((c->ahead.unjoined >> k & 1u) && c->lane_done[k]) (void)hipStreamWaitEvent(c->stream, c->lane_done[k], 0);
+    c->ahead.unjoined = 0;
 }
-static void ahead_discard(rt_context* c) {
-    c->ahead.valid = c->ahead.next_valid = false;
-    lanes_join(c);
-}
+static void ahead_discard(rt_context* c) { c->ahead.valid = c->ahead.next_valid = false; }
 static void ahead_reset(rt_context* c) {
     ahead_discard(c);
+    lanes_join(c);
     c->ahead.have_last = false;
     c->ahead.streak = 0;
 }
@@ -438,7 +441,7 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
     const uint32_t batch = paths_batch(pixels);
     const size_t want_bytes = (size_t)RT_LANES * batch * pixels * sizeof(float4);  // one slot of `batch` frames per lane
     if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries) return RT_OK;
-    ahead_discard(c);
+    ahead_reset(c);  // launches traced ahead still write the staging area that is about to be freed
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (want_bytes > c->samples_bytes) {
         dfree(c->d_samples);
@@ -593,6 +596,9 @@ static int ensure_primary_hits(rt_context* c, const DCamera& dc, const rt_params
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->phits_ready, c->stream));
+    // the pass used the first spill copy: a later launch on an internal stream -- also one that does not read the hits and
+    // so does not wait on phits_ready -- must not start on it before the pass has finished
+    for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipEventRecord(c->slot_free[k], c->stream));
     std::memcpy(&c->phits_cam, &dc, sizeof dc);
     c->phits_band = p->band;
     c->phits_valid = true;
@@ -631,6 +637,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     } else {
         // slot 0 and the first spill copy may still be in use by an internal stream's kernel
         for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamWaitEvent(pst, c->lane_done[k], 0));
+        c->ahead.unjoined = 0;  // pst is the context's stream
     }
     if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
     {
@@ -641,6 +648,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (pipelined) {
         HIPCHK(c, hipEventRecord(c->lane_done[slot], pst));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[slot], 0));
+        c->ahead.unjoined &= ~(1u << slot);  // the wait also covers discarded launches that ran on this stream before
     }
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
@@ -668,7 +676,7 @@ static int launch_ahead(rt_context* c, const DCamera& dc, const rt_params* p, ui
     launch_k_paths(c, dc, a, false, (p->flags & RT_FLAG_FIX_INVDIR) != 0, PM_TRACE, true, pst);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->lane_done[slot], pst));
-    c->ahead.unjoined = true;
+    c->ahead.unjoined |= 1u << slot;
     return RT_OK;
 }
 
@@ -735,7 +743,7 @@ static int frame_call(rt_context* c, const DCamera& dc, const rt_params* p, uint
     fill_paths_args(c, p, bl, frame_count, 1u, 1u, a);
     a.samples = c->d_samples + (size_t)ah.slot * (c->samples_bytes / RT_LANES / sizeof(float4)) + (size_t)j * pixels;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane_done[ah.slot], 0));
-    if (!ah.next_valid) c->ahead.unjoined = false;  // every launch in flight now has a waiter on the context's stream
+    c->ahead.unjoined &= ~(1u << ah.slot);  // everything launched on that internal stream so far now has a waiter on the context's stream
     {
         LaunchTimer lt(c, RT_K_ACCUMULATE);
         launch_k_accumulate(c, p, bl, a, prev, out);
@@ -781,20 +789,20 @@ int rt_create(int device_id, rt_context** out_ctx) {
         rt_destroy(c);
         return rc;
     }
-    // The internal streams have the caller's default priority.  Streams of one priority share a small pool of hardware
-    // queues (4 per process by default): in a process that holds many streams -- PyTorch creates 32 with its first
-    // torch.cuda.Stream -- an internal stream can land on the hardware queue of the other one or of the caller's stream,
-    // and launches that are meant to overlap then run one after the other (frame-by-frame loop 0.54 -> 0.67 ms per
-    // frame).  Streams of another priority come from another pool (RT_TUNE_LANE_PRIORITY = 1 lowest / -1 highest), but
-    // with the lowest priority a process that also runs RCCL collectives hung on the GPU box (the collective's queue
-    // waits on an event of a queue that is never scheduled), so this is a tuning knob, not the default; callers that
-    // can should issue their own work on the context's stream (rt_get_stream) instead of adding streams.
-    int prio_low = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    int lane_prio = 0;
-    if (const char* ev = getenv("RT_TUNE_LANE_PRIORITY")) lane_prio = atoi(ev) < 0 ? prio_high : (atoi(ev) > 0 ? prio_low : 0);
+    // The internal streams have the caller's default priority and must keep it.  Streams of one priority share a small
+    // pool of hardware queues (4 per process by default): in a process that holds many streams -- PyTorch creates 32 with
+    // its first torch.cuda.Stream -- an internal stream can land on the hardware queue of the other one or of the
+    // caller's stream, and launches that are meant to overlap then run one after the other (frame-by-frame loop 0.54 ->
+    // 0.67 ms per frame); callers that can should issue their own work on the context's stream (rt_get_stream) instead
+    // of adding streams.  Lower-priority internal streams come from another queue pool and avoid that sharing, but they
+    // invert the dependency order of this library: the context's stream (normal priority) holds a barrier packet that
+    // waits for lane_done of a path kernel on a lower-priority queue, and every stream that in turn waits on the
+    // context's stream -- a collective library's own stream does, through the event it records there -- holds another.
+    // The queue arbiter serves a lower-priority queue only when no queue above it has a packet at its head, and a barrier
+    // packet whose signal has not fired is such a packet: the kernel everybody waits for is never dispatched.  A process
+    // with RCCL collectives hung that way on the GPU box with lowest-priority lanes, so the priority is not configurable.
     for (int k = 0; k < RT_LANES; k++) {
-        if ((e = hipStreamCreateWithPriority(&c->lane_stream[k], hipStreamNonBlocking, lane_prio)) != hipSuccess ||
+        if ((e = hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming)) != hipSuccess) {
             int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
@@ -802,6 +810,9 @@ int rt_create(int device_id, rt_context** out_ctx) {
             return rc;
         }
     }
+#ifdef RT_TUNABLES
+    // Tuning builds only (librt_hip_tune.so, used by tools/ and by the tests that cross-check a non-default variant): the
+    // scheduling parameters can be overridden from the environment, read once here.  The shipped library reads none.
     if (const char* e = getenv("RT_TUNE_W_INNER")) c->tune_w_inner = atoi(e);
     if (const char* e = getenv("RT_TUNE_W_LEAF")) c->tune_w_leaf = atoi(e);
     if (const char* e = getenv("RT_TUNE_MIN_TRAV")) c->tune_min_trav = atoi(e);
@@ -812,6 +823,10 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_AHEAD")) c->tune_ahead = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_BLOCKS")) c->tune_frame_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_CHUNK")) c->tune_frame_chunk = atoi(e);
+    if (const char* e = getenv("RT_TUNE_PACKETS")) c->tune_packets = atoi(e);
+    if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
+    if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
     // out-of-range values would stall the kernel's phase switching: a traversal threshold above the lanes that can
     // traverse while some wait for a refill would send the wave back and forth without progress
     auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -822,9 +837,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->tune_w_leaf = clamp(c->tune_w_leaf, 1, 64);
     c->tune_frame_blocks = clamp(c->tune_frame_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
-    if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
-    if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
+#endif
     hipDeviceProp_t prop;
     c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
                      ? prop.multiProcessorCount : 256;

@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -34,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -129,11 +131,17 @@ struct Rccl {
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
     }
     // rank 0 creates the id and publishes it through the file (written under another name, then renamed, so that a
-    // reader never sees half of it); the other ranks wait for the file
+    // reader never sees half of it); the other ranks wait for the file.  A file left behind by an earlier run must not be
+    // mistaken for this run's: rank 0 removes any before it publishes and removes its own once ncclCommInitRank has
+    // returned (every rank has read it by then: the call completes only when all ranks have joined), and the other
+    // ranks ignore a file written more than a minute before they started (all ranks of a run are on one node and are
+    // started together).  Communicators of more than one rank have not run on hardware yet: the build box has one GPU.
     void init(const std::string& id_file, int rank, int world) {
+        const time_t started = std::time(nullptr);
         load();
         ncclUniqueId id;
         if (rank == 0) {
+            (void)std::remove(id_file.c_str());
             check(GetUniqueId(&id), "ncclGetUniqueId");
             const std::string tmp = id_file + ".tmp";
             FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -143,16 +151,20 @@ struct Rccl {
         } else {
             bool ok = false;
             for (int tries = 0; tries < 1200 && !ok; tries++) {  // up to two minutes
-                FILE* f = std::fopen(id_file.c_str(), "rb");
-                if (f) {
-                    ok = std::fread(&id, sizeof id, 1, f) == 1;
-                    std::fclose(f);
+                struct stat sb;
+                if (stat(id_file.c_str(), &sb) == 0 && sb.st_mtime + 60 >= started) {
+                    FILE* f = std::fopen(id_file.c_str(), "rb");
+                    if (f) {
+                        ok = std::fread(&id, sizeof id, 1, f) == 1;
+                        std::fclose(f);
+                    }
                 }
                 if (!ok) usleep(100000);
             }
-            if (!ok) throw std::runtime_error("no ncclUniqueId appeared in " + id_file);
+            if (!ok) throw std::runtime_error("no ncclUniqueId of this run appeared in " + id_file);
         }
         check(CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        if (rank == 0) (void)std::remove(id_file.c_str());
     }
     void shutdown() {
         if (comm) (void)CommDestroy(comm);

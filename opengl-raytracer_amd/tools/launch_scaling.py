@@ -14,7 +14,7 @@ def main():
     pkg = entry.load_package()
     pos = {"dragon80k": (0.0, 0.0, -4.5), "teapot": (0.0, 0.0, -2.0)}.get(scene, (0.0, 0.0, -2.0))
     cam = pkg.make_camera(pos=pos)
-    ctx = pkg.RenderContext(0)
+    ctx = pkg.RenderContext(0, tunable=any(k.startswith(("RT_TUNE_", "RT_BUILD_")) for k in os.environ))
     ctx.upload_scene(pkg.load_scene(os.path.join(ROOT, "fixtures", scene + ".obj"), colour_seed=1))
     W, H = 1920, 1080
     buf = pkg.DeviceBuffer(W * H * 16)

@@ -36,7 +36,7 @@ def main():
         pos = (0.0, 0.0, -5.5) if a.scene == "dragon80k" else (0.0, 0.0, -2.0)
     v, f = v.astype(np.float32), f.astype(np.uint32)
     col = pkg.make_colours(1, f.shape[0])
-    ctx = pkg.RenderContext(0)
+    ctx = pkg.RenderContext(0, tunable=any(k.startswith(("RT_TUNE_", "RT_BUILD_")) for k in os.environ))
     for r in range(a.repeat):
         t0 = time.perf_counter()
         rc = ctx.lib.rt_build_scene_device(ctx.ctx, pkg.fptr(v), v.shape[0], f.ctypes.data_as(pkg.c_uint32_p), f.shape[0], pkg.fptr(col))

@@ -32,7 +32,7 @@ def main():
     pkg = entry.load_package()
     obj, pos = SCENES[a.scene]
     cam = pkg.make_camera(pos=pos)
-    ctx = pkg.RenderContext(0)
+    ctx = pkg.RenderContext(0, tunable=any(k.startswith(("RT_TUNE_", "RT_BUILD_")) for k in os.environ))
     if obj is None:
         import numpy as np
 

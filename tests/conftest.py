@@ -64,15 +64,18 @@ def rrmse(a: np.ndarray, b: np.ndarray) -> float:
 
 
 def render_both_ways(pkg, ctx, cam, params, want, cnt_o, start=None, nan_ok=False, what=""):
-    """Renders `params` twice with work counters, as asked and again with RT_FLAG_NO_CULL, and holds both to the oracle's
-    image bit for bit.  The uncut render must also show the oracle's six work counters exactly.  The default render may
-    skip subtrees a bounce ray cannot reach: it must trace the same rays, find the same hits and finish the same paths
-    (counters 2, 3, 5) with no more box tests, triangle tests and node visits (0, 1, 4) than the reference runs.
-    Returns the default render and its counters."""
+    """Renders `params` three times and holds every image to the oracle's bit for bit: with work counters as asked, with
+    work counters and RT_FLAG_NO_CULL, and exactly as asked WITHOUT counters -- the instantiation a timed run executes (its
+    traversal steps end in hand-scheduled code that counting builds do not take).  The uncut render must also show the
+    oracle's six work counters exactly.  The default render may skip subtrees a bounce ray cannot reach: it must trace
+    the same rays, find the same hits and finish the same paths (counters 2, 3, 5) with no more box tests, triangle
+    tests and node visits (0, 1, 4) than the reference runs.  Returns the default counting render and its counters."""
     out = None
-    for no_cull in (False, True):
+    for variant in ("counted", "uncut", "timed"):
+        no_cull = variant == "uncut"
         p = type(params).from_buffer_copy(params)
-        p.flags |= pkg.RT_FLAG_COUNTERS | (pkg.RT_FLAG_NO_CULL if no_cull else 0)
+        if variant != "timed":
+            p.flags |= pkg.RT_FLAG_COUNTERS | (pkg.RT_FLAG_NO_CULL if no_cull else 0)
         ctx.reset_counters()
         got = ctx.render(cam, p, None if start is None else start.copy())
         cnt = ctx.counters()
@@ -82,12 +85,14 @@ def render_both_ways(pkg, ctx, cam, params, want, cnt_o, start=None, nan_ok=Fals
         if not same.all():
             bad = (~same).any(axis=-1)
             ys, xs = np.nonzero(bad)
-            raise AssertionError(f"{what} (no_cull={no_cull}): {int(bad.sum())} of {bad.size} pixels differ; first at "
+            raise AssertionError(f"{what} ({variant}): {int(bad.sum())} of {bad.size} pixels differ; first at "
                                  f"(x={xs[0]}, y={ys[0]}): got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]}")
-        if no_cull:
+        if variant == "uncut":
             assert np.array_equal(cnt, cnt_o), f"{what}: work counters of the uncut render differ: gpu {cnt} oracle {cnt_o}"
-        else:
+        elif variant == "counted":
             assert np.array_equal(cnt[[2, 3, 5]], cnt_o[[2, 3, 5]]), f"{what}: rays/hits/paths differ: gpu {cnt} oracle {cnt_o}"
             assert (cnt[[0, 1, 4]] <= cnt_o[[0, 1, 4]]).all(), f"{what}: more work than the reference: gpu {cnt} oracle {cnt_o}"
             out = (got, cnt)
+        elif not (params.flags & pkg.RT_FLAG_COUNTERS):
+            assert not cnt.any(), f"{what}: a render without RT_FLAG_COUNTERS counted {cnt}"
     return out

@@ -169,6 +169,24 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in out
 
 
+def test_shipped_library_reads_no_tuning_environment(pkg):
+    """The scheduling parameters of the kernels are compile-time defaults in librt_hip.so: only the tuning build
+    (librt_hip_tune.so, -DRT_TUNABLES, loaded by tools/ and by the tests that cross-check a non-default variant) knows
+    the RT_TUNE_* / RT_BUILD_* environment variables, and neither knows a priority for the internal streams any more
+    (lowest-priority internal streams deadlocked a process that also ran collectives)."""
+    csrc = os.path.join(ROOT, "opengl-raytracer_amd", "csrc")
+    shipped = open(os.path.join(csrc, "librt_hip.so"), "rb").read()
+    tune = open(os.path.join(csrc, "librt_hip_tune.so"), "rb").read()
+    for needle in (b"RT_TUNE_", b"RT_BUILD_GEN", b"RT_BUILD_SMALL_MAX", b"RT_BUILD_TINY"):
+        assert needle not in shipped, needle
+    assert b"RT_TUNE_CULL_REACH" in tune and b"RT_BUILD_GEN" in tune
+    assert b"LANE_PRIORITY" not in shipped and b"LANE_PRIORITY" not in tune
+    lib = pkg.load_hip(tunable=True)
+    for name in pkg.HIP_SYMBOLS:
+        assert hasattr(lib, name), name
+    assert lib.rt_version() == pkg.load_hip().rt_version()   # same sources, same build id
+
+
 def test_no_gpu_means_loud_failure(pkg):
     """Without a GPU rt_create must fail with a message (there is no CPU fallback); with one it succeeds."""
     hip = pkg.load_hip()

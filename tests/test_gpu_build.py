@@ -135,7 +135,7 @@ def _canonical(scene):
     return rows, per_face
 
 
-BUILDER_VARIANTS = {  # environment read by rt_create
+BUILDER_VARIANTS = {  # environment read by rt_create of the tuning build (librt_hip_tune.so); {} runs the shipped library
     "level loop only": {"RT_BUILD_GEN": "1"},
     "default": {},
     "small 128, tiny 4": {"RT_BUILD_SMALL_MAX": "128", "RT_BUILD_TINY": "4"},
@@ -156,7 +156,7 @@ def test_small_subtree_kernel_builds_the_same_tree_as_the_level_loop(pkg, name):
     for variant, env in BUILDER_VARIANTS.items():
         os.environ.update(env)
         try:
-            ctx = pkg.RenderContext(0)
+            ctx = pkg.RenderContext(0, tunable=bool(env))
         finally:
             for k in env:
                 del os.environ[k]
@@ -354,7 +354,7 @@ def test_device_build_degenerate_inputs(pkg, oracle):
     for variant in ("level loop only", "default"):
         os.environ.update(BUILDER_VARIANTS[variant])
         try:
-            ctx = pkg.RenderContext(0)
+            ctx = pkg.RenderContext(0, tunable=bool(BUILDER_VARIANTS[variant]))
         finally:
             for k in BUILDER_VARIANTS[variant]:
                 del os.environ[k]

@@ -129,10 +129,11 @@ def test_cull_on_device_built_and_refitted_trees(pkg, oracle):
 @pytest.mark.parametrize("reach", ["0", "1"])
 def test_cull_with_either_pad_rule(pkg, oracle, scenes, reach):
     """The pad is either one constant per scene or grows with a box's reach from the ray origin; the library picks by the
-    scene's size against its triangles.  Both forced here (RT_TUNE_CULL_REACH is read when a context is created)."""
+    scene's size against its triangles.  Both forced here (the tuning build of the library reads RT_TUNE_CULL_REACH when a
+    context is created; the shipped one reads no environment)."""
     os.environ["RT_TUNE_CULL_REACH"] = reach
     try:
-        ctx = pkg.RenderContext(0)
+        ctx = pkg.RenderContext(0, tunable=True)
     finally:
         del os.environ["RT_TUNE_CULL_REACH"]
     for name, pos, yaw in (("dragon80k", (0.0, 0.0, -5.5), 0.0), ("dragon80k", (0.2, 0.4, -1.0), 0.5), ("teapot", (0.0, 0.0, -2.0), -0.2)):
