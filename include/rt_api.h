@@ -70,6 +70,16 @@ extern "C" {
                                      path starts at its first bounce.  Pixels are bit-identical; rt_counters() then counts the
                                      rays actually traced (the primary pass once + bounce rays).  Default pipeline only. */
 
+#define RT_FLAG_PACKETS 0x80u      /* trace the primary rays tile by tile whatever the library's own estimate says.  By default
+                                     the default pipeline decides per launch: where triangles are large against a pixel's
+                                     footprint (estimated from the root box, the triangle count and the camera) the 64 primary
+                                     rays of every 8x8-pixel tile walk the BVH together, one node fetch per wave, each ray in
+                                     the reference's own visit order (raytrace.glsl:127-195); elsewhere, and with
+                                     RT_FLAG_FIX_INVDIR, every lane follows its own ray.  Same pixels and counters either way;
+                                     the flag exists so that tests and measurements can pin the choice.  Ignored with
+                                     RT_FLAG_NO_CULL (the literal lane-by-lane traversal), RT_FLAG_REUSE_PRIMARY and on the
+                                     other pipelines.  No counterpart in the reference. */
+
 /* Scene in the layout the reference uploads (raytrace.cpp:38-54, scene-loader.h:7-15):
  *   nodes    num_nodes x 12 floats, AlignedMat3 {min.xyz,_}{max.xyz,_}{isLeaf,a,b,_};
  *            leaf iff |isLeaf-1| <= 1e-4, a..b inclusive triangle range, else child ids
@@ -250,7 +260,8 @@ int rt_reset_counters(rt_context* ctx);
 #define RT_K_ACCUMULATE 4
 #define RT_K_MEGA 5
 #define RT_K_PATHS 6
-#define RT_NUM_KERNEL_CLASSES 7
+#define RT_K_PRIMARY 7   /* primary rays traced tile by tile ahead of the path kernel */
+#define RT_NUM_KERNEL_CLASSES 8
 /* enable != 0: bracket every kernel launch with HIP events on the context's stream (adds
  * event overhead; keep it off in throughput runs).  rt_kernel_times synchronises and
  * returns the summed milliseconds and launch counts per class since profiling was enabled

@@ -27,10 +27,11 @@ RT_FLAG_COUNTERS = 0x8
 RT_FLAG_WAVEFRONT = 0x10
 RT_FLAG_REUSE_PRIMARY = 0x20
 RT_FLAG_NO_CULL = 0x40
+RT_FLAG_PACKETS = 0x80
 RT_BAND_INTERLEAVED = 0x8000
 RT_NUM_COUNTERS = 6
-RT_NUM_KERNEL_CLASSES = 7
-KERNEL_CLASS_NAMES = ["generate", "extend", "shade", "tail", "accumulate", "mega", "paths"]
+RT_NUM_KERNEL_CLASSES = 8
+KERNEL_CLASS_NAMES = ["generate", "extend", "shade", "tail", "accumulate", "mega", "paths", "primary"]
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)

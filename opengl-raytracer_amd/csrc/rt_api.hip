@@ -24,6 +24,7 @@
 #include "rt_api.h"
 #include "rt_device.h"
 #include "rt_paths.h"
+#include "rt_packets.h"
 #include "rt_frame_kernels.h"
 #include "rt_build.h"
 
@@ -143,12 +144,20 @@ struct rt_context {
     DCamera phits_cam{};
     uint32_t phits_band = 0;
     hipEvent_t phits_ready = nullptr;  // recorded on the context's stream after the pass that fills d_phits
+    // primary rays traced per tile by k_primary (rt_packets.h): the hits it queues for the path kernel, one share per
+    // pipeline slot like the staged samples
+    float4* d_hitq = nullptr;
+    uint32_t* d_hcount = nullptr;
+    size_t hitq_items = 0;        // (tile, frame) items the two buffers hold, all slots together
     uint2* d_pspill = nullptr;    // stack spill area, one copy per pipeline slot
     size_t pspill_entries = 0;
     // Launches of the path kernel are pipelined: consecutive launches (the frames of a frame-by-frame loop, the batches
     // of a multi-frame call) rotate over RT_LANES internal streams, so that the next one fills the chip while the last
     // long paths of a launch drain; only the accumulate kernels,
     // which carry the frame-to-frame dependency, are ordered on the context's stream.
+    hipEvent_t prim_done[RT_LANES] = {};   // recorded on lane_stream[k] after the primary pass that filled slot k's hit queues
+    bool prim_pending = false;             // prim_done[prim_last] has been recorded by a pipelined launch
+    uint32_t prim_last = 0;
     hipStream_t lane_stream[RT_LANES] = {};
     hipEvent_t lane_done[RT_LANES] = {};   // recorded on lane_stream[k] after its path kernel
     hipEvent_t slot_free[RT_LANES] = {};   // recorded on the context's stream after the accumulate that read slot k
@@ -177,13 +186,18 @@ struct rt_context {
     CullPad cull;
     float tune_cull_slack = -2.0f;  // RT_TUNE_CULL_SLACK: >= -1 overrides the scene's value with a constant one (diagnostics)
     int tune_cull_reach = -1;       // RT_TUNE_CULL_REACH: 0 / 1 forces the constant / the reach-dependent pad
-    int tune_min_trav = PT_MIN_TRAV, tune_min_service = PT_MIN_SERVICE, tune_w_inner = PT_W_INNER, tune_w_leaf = PT_W_LEAF;
+    int tune_min_trav = 0, tune_min_service = 0;   // phase-switch thresholds; 0: by the kind of launch (paths_thresholds)
+    int tune_w_inner = PT_W_INNER, tune_w_leaf = PT_W_LEAF;
     int tune_cache = -1;  // >= 0: stage at most this many records in LDS
     // workgroups per CU of a launch that renders a single frame: with one, the launches of two consecutive frames are
     // resident side by side for their whole duration and each fills the issue slots the other's drain leaves idle
     int tune_frame_blocks = 1;
     int tune_frame_chunk = 1;                  // PathsArgs::chunk of such a launch
-    int tune_packets = 1;                      // 0: primary rays are traced lane by lane like bounce rays (A/B runs)
+    int tune_batch_blocks = PT_BLOCKS_PER_CU;  // workgroups per CU of a pipelined launch of several frames
+    int tune_overlap = 1;                      // 0: the batches of a call run one after the other on the context's stream (A/B runs)
+    int tune_stagger = 1;                      // 1: the primary pass of a pipelined launch waits for the previous launch's (launch_paths_batch)
+    int tune_queue_blocks = 1;                 // workgroups per CU of a pipelined path launch that starts from k_primary's hit queues
+    int tune_packets = 1;                      // primary rays traced tile by tile: 1 by rule (use_packets), 0 never, 2 always (A/B runs)
 
     unsigned long long* d_counters = nullptr;
     unsigned char* scratch_ptr = nullptr;  // this device's copy of the static scratch array (rt_raytrace_frame_noalloc)
@@ -312,6 +326,9 @@ static void free_buffers(rt_context* c) {
     c->samples_bytes = 0;
     dfree(c->d_pspill);
     c->pspill_entries = 0;
+    dfree(c->d_hitq);
+    dfree(c->d_hcount);
+    c->hitq_items = 0;
     dfree(c->d_phits);
     c->phits_pixels = 0;
     c->phits_valid = false;
@@ -435,12 +452,20 @@ static void ahead_reset(rt_context* c) {
     c->ahead.streak = 0;
 }
 
-static int ensure_paths_buffers(rt_context* c, size_t pixels) {
+// Work items (8x8 tiles, whole strips of PT_STRIP_W tile columns) of one frame of a width x height image.
+static size_t items_per_frame(int width, int height) {
+    const size_t tx = ((size_t)(width + 7) / 8 + PT_STRIP_W - 1) / PT_STRIP_W * PT_STRIP_W;
+    return tx * (size_t)((height + 7) / 8);
+}
+
+static int ensure_paths_buffers(rt_context* c, int width, int height) {
+    const size_t pixels = (size_t)width * height;
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
     // sized in bytes: a smaller image may render more frames per launch than the one the buffer was made for
     const uint32_t batch = paths_batch(pixels);
     const size_t want_bytes = (size_t)RT_LANES * batch * pixels * sizeof(float4);  // one slot of `batch` frames per lane
-    if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries) return RT_OK;
+    const size_t want_items = (size_t)RT_LANES * batch * items_per_frame(width, height);
+    if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries && want_items <= c->hitq_items) return RT_OK;
     ahead_reset(c);  // launches traced ahead still write the staging area that is about to be freed
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (want_bytes > c->samples_bytes) {
@@ -448,6 +473,14 @@ static int ensure_paths_buffers(rt_context* c, size_t pixels) {
         c->samples_bytes = 0;
         HIPCHK(c, hipMalloc(&c->d_samples, want_bytes));
         c->samples_bytes = want_bytes;
+    }
+    if (want_items > c->hitq_items) {
+        dfree(c->d_hitq);
+        dfree(c->d_hcount);
+        c->hitq_items = 0;
+        HIPCHK(c, hipMalloc(&c->d_hitq, want_items * 64 * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_hcount, want_items * sizeof(uint32_t)));
+        c->hitq_items = want_items;
     }
     if (want_spill > c->pspill_entries) {
         dfree(c->d_pspill);
@@ -522,8 +555,8 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.total_tiles = nframes * (uint32_t)a.tiles_per_frame;
     a.pixels = (uint32_t)((size_t)p->width * p->height);
     a.cache_recs = c->cache_recs < PT_CACHE ? c->cache_recs : PT_CACHE;
-    a.min_trav = c->tune_min_trav;
-    a.min_service = c->tune_min_service;
+    a.min_trav = PT_MIN_TRAV;          // launch_k_paths sets the thresholds once the launch's mode is known
+    a.min_service = PT_MIN_SERVICE;
     a.cull_slack = (p->flags & RT_FLAG_NO_CULL) ? -1.0f : (c->tune_cull_slack >= -1.0f ? c->tune_cull_slack : c->cull.slack);
     a.cull_slope = c->tune_cull_slack >= -1.0f ? 0.0f : c->cull.slope;
     a.w_inner = c->tune_w_inner;
@@ -531,6 +564,8 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.chunk = nframes == 1 ? (uint32_t)c->tune_frame_chunk : 1u;
     if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
     a.hits = nullptr;
+    a.hitq = nullptr;
+    a.hcount = nullptr;
     a.samples = nullptr;
     a.spill = nullptr;
     a.spill_stride = (size_t)c->num_cus * PT_BLOCKS_PER_CU * PT_BLOCK;
@@ -539,21 +574,85 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
 
 // overlapped: the launch shares the chip with the launch before or after it (pipelined calls); a single-frame launch then
 // takes tune_frame_blocks workgroups per CU, any other launch fills the chip.
-static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& a, bool count, bool fix, int pmode, bool overlapped,
+// When a wave leaves its traversal phase (fewer than min_trav lanes still traverse) and its service phase (fewer than
+// min_service lanes wait).  Measured per kind of launch (tools/tune_queue*.sh; dragon80k / teapot / 3840x2160, ms per frame):
+//   paths that start from k_primary's hit queues: every refill runs the bounce code, so a wave should serve rarely and
+//     many lanes at once: 40/16 -> 10/6: 0.293 -> 0.268, 0.205 -> 0.189, 1.02 -> 0.93;
+//   primary rays traced lane by lane, stale invDir: 40/16 -> 16/6: 0.301 -> 0.290, 0.231 -> 0.221, 1.078 -> 1.03
+//     (9.27 M-triangle grid 0.99, unchanged);
+//   RT_FLAG_FIX_INVDIR (long paths, most lanes carry bounce rays): 40/16 stays (16/6: 0.508 -> 0.527).
+static void paths_thresholds(const rt_context* c, bool fix, int pmode, PathsArgs& a) {
+    a.min_trav = fix ? PT_MIN_TRAV : (pmode == PM_QUEUE || pmode == PM_REUSE ? 10 : 16);
+    a.min_service = fix ? PT_MIN_SERVICE : 6;
+    if (c->tune_min_trav > 0) a.min_trav = c->tune_min_trav;
+    if (c->tune_min_service > 0) a.min_service = c->tune_min_service;
+}
+
+static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& args, bool count, bool fix, int pmode, bool overlapped,
                            hipStream_t st) {
+    PathsArgs a = args;
+    paths_thresholds(c, fix, pmode, a);
     // (the spill area is sized for the full grid; a smaller grid uses a prefix of it)
-    dim3 grid(c->num_cus * (overlapped && a.num_frames == 1 ? c->tune_frame_blocks : PT_BLOCKS_PER_CU)), blk(PT_BLOCK);
+    // Workgroups per CU.  A launch that has the chip to itself fills it (2 x 16 waves per CU).  Pipelined launches share it:
+    // a single-frame launch takes one workgroup per CU, so that two consecutive frames are resident side by side; so does a
+    // launch that starts from k_primary's hit queues, which leaves half of every CU's LDS and wave slots to the next
+    // launch's primary pass -- that pass is dense arithmetic, this kernel waits on memory most of the time, and next to each
+    // other they fill each other's gaps (dragon80k, bench.py --steps 20 / 128: 11.8 -> 12.1 / 12.0 -> 12.4 Grays/s).
+    const int per_cu = !overlapped ? PT_BLOCKS_PER_CU : a.num_frames == 1 ? c->tune_frame_blocks : pmode == PM_QUEUE ? c->tune_queue_blocks
+                                                                                                                 : c->tune_batch_blocks;
+    dim3 grid(c->num_cus * per_cu), blk(PT_BLOCK);
 #define PATHS(C_, F_, M_) hipLaunchKernelGGL((k_paths<C_, F_, M_>), grid, blk, 0, st, c->sc, dc, a)
     if (pmode == PM_PRIMARY) {  // no bounces in this pass: invDir handling does not matter
         if (count) PATHS(true, false, PM_PRIMARY); else PATHS(false, false, PM_PRIMARY);
     } else if (pmode == PM_REUSE) {
         if (count) { if (fix) PATHS(true, true, PM_REUSE); else PATHS(true, false, PM_REUSE); }
         else { if (fix) PATHS(false, true, PM_REUSE); else PATHS(false, false, PM_REUSE); }
+    } else if (pmode == PM_QUEUE) {
+        if (count) { if (fix) PATHS(true, true, PM_QUEUE); else PATHS(true, false, PM_QUEUE); }
+        else { if (fix) PATHS(false, true, PM_QUEUE); else PATHS(false, false, PM_QUEUE); }
     } else {
         if (count) { if (fix) PATHS(true, true, PM_TRACE); else PATHS(true, false, PM_TRACE); }
         else { if (fix) PATHS(false, true, PM_TRACE); else PATHS(false, false, PM_TRACE); }
     }
 #undef PATHS
+}
+
+// Does a launch with these parameters trace its primary rays tile by tile (k_primary) ahead of the path kernel?
+// RT_FLAG_NO_CULL asks for the reference's literal lane-by-lane traversal; RT_FLAG_REUSE_PRIMARY has its own pass.
+//
+// A packet pays when the 64 rays of a tile visit much the same nodes, i.e. when triangles are large against a tile's
+// footprint.  Estimated from what the host knows without looking at the mesh: triangle size ~ sqrt(surface of the root
+// box / triangles), pixel footprint at the distance of the root box's centre.  Measured (ms per frame, lane by lane ->
+// packets): teapot (65 pixels per triangle) 0.221 -> 0.189, dragon80k 1080p (7 pixels) 0.290 -> 0.268, 3840x2160 (15
+// pixels) 1.03 -> 0.93, 9.27 M-triangle grid (1 pixel: a tile's rays part ways a few levels down) 0.99 -> 1.12.  With
+// RT_FLAG_FIX_INVDIR most of the work is bounce rays and splitting the primary rays off loses (0.51 -> 0.58).
+static bool use_packets(const rt_context* c, const rt_params* p, const DCamera& dc) {
+    if (c->tune_packets == 0 || (p->flags & (RT_FLAG_NO_CULL | RT_FLAG_REUSE_PRIMARY))) return false;
+    if (c->tune_packets >= 2 || (p->flags & RT_FLAG_PACKETS)) return true;
+    if (p->flags & RT_FLAG_FIX_INVDIR) return false;
+    const double ex = (double)c->sc.rmax[0] - c->sc.rmin[0], ey = (double)c->sc.rmax[1] - c->sc.rmin[1], ez = (double)c->sc.rmax[2] - c->sc.rmin[2];
+    const double area = 2.0 * (ex * ey + ey * ez + ez * ex);
+    double dist2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+        const double m = 0.5 * ((double)c->sc.rmax[k] + c->sc.rmin[k]) - dc.pos[k];
+        dist2 += m * m;
+    }
+    const double tri = std::sqrt(area / (double)(c->num_tris > 0 ? c->num_tris : 1));
+    const double pixel = (double)dc.pixel_width / (double)dc.viewport_dist * std::sqrt(dist2);
+    return tri >= 3.0 * pixel;   // NaN (degenerate box or camera): false
+}
+
+// Points the launch at pipeline slot `slot`'s share of the hit queues and traces the primary rays of its items on `st`;
+// the path kernel that follows on the same stream runs in PM_QUEUE mode.
+static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, bool count, hipStream_t st) {
+    const size_t share = c->hitq_items / RT_LANES;
+    a.hitq = c->d_hitq + (size_t)slot * share * 64;
+    a.hcount = c->d_hcount + (size_t)slot * share;
+    dim3 grid(c->num_cus * PK_BLOCKS_PER_CU), blk(PK_BLOCK);
+    if (count)
+        hipLaunchKernelGGL((k_primary<true>), grid, blk, 0, st, c->sc, dc, a);
+    else
+        hipLaunchKernelGGL((k_primary<false>), grid, blk, 0, st, c->sc, dc, a);
 }
 
 static void launch_k_accumulate(const rt_context* c, const rt_params* p, const BandLayout& bl, const PathsArgs& a, const float4* prev,
@@ -605,6 +704,20 @@ static int ensure_primary_hits(rt_context* c, const DCamera& dc, const rt_params
     return RT_OK;
 }
 
+// The primary pass of a pipelined launch, on the launch's internal stream `pst`.
+// Primary passes run one after the other: this one starts when the previous launch's has finished, i.e. next to that
+// launch's path kernel rather than next to its primary pass.  Two primary passes side by side only slow each other down,
+// and the two path kernels after them then start together and drain together (bench.py --steps 20 on dragon80k:
+// 9.9 -> 11.8 Grays/s).
+static int launch_k_primary_pipelined(rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, hipStream_t pst) {
+    if (c->tune_stagger && c->prim_pending && c->prim_last != slot) HIPCHK(c, hipStreamWaitEvent(pst, c->prim_done[c->prim_last], 0));
+    launch_k_primary(c, dc, a, slot, false, pst);
+    HIPCHK(c, hipEventRecord(c->prim_done[slot], pst));
+    c->prim_pending = true;
+    c->prim_last = slot;
+    return RT_OK;
+}
+
 // Renders `nframes` (<= PT_MAX_BATCH) frames frame_base, frame_base+stride, ... concurrently and folds
 // them, in order, into out (reading prev).  pipelined: the path kernel goes to one of the internal streams in turn
 // (see rt_context::lane_stream) and overlaps with the previous launch's; the accumulate kernel, which carries the
@@ -613,12 +726,11 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
                               uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined) {
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
-    size_t pixels = (size_t)p->width * p->height;
     ahead_discard(c);  // this launch takes a staging slot of its own
-    int rc = ensure_paths_buffers(c, pixels);
+    int rc = ensure_paths_buffers(c, p->width, p->height);
     if (rc != RT_OK) return rc;
     // counters and per-kernel timing are read on the context's stream: such calls stay on it
-    if (count || c->profiling) pipelined = false;
+    if (count || c->profiling || c->tune_overlap == 0) pipelined = false;
     const uint32_t slot = pipelined ? (c->lane_next++ % RT_LANES) : 0u;
     hipStream_t pst = pipelined ? c->lane_stream[slot] : c->stream;
     const BandLayout bl = band_layout(p);
@@ -640,9 +752,16 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
         c->ahead.unjoined = 0;  // pst is the context's stream
     }
     if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
+    const bool packets = use_packets(c, p, dc);
+    if (packets && pipelined) {
+        if ((rc = launch_k_primary_pipelined(c, dc, a, slot, pst)) != RT_OK) return rc;
+    } else if (packets) {
+        LaunchTimer lt(c, RT_K_PRIMARY);
+        launch_k_primary(c, dc, a, slot, count, pst);
+    }
     {
         LaunchTimer lt(c, RT_K_PATHS);
-        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : PM_TRACE, pipelined, pst);
+        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : (packets ? PM_QUEUE : PM_TRACE), pipelined, pst);
     }
     HIPCHK(c, hipGetLastError());
     if (pipelined) {
@@ -673,7 +792,10 @@ static int launch_ahead(rt_context* c, const DCamera& dc, const rt_params* p, ui
     a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * a.spill_stride : nullptr;
     hipStream_t pst = c->lane_stream[slot];
     HIPCHK(c, hipStreamWaitEvent(pst, c->slot_free[slot], 0));  // the slot's last reader has finished
-    launch_k_paths(c, dc, a, false, (p->flags & RT_FLAG_FIX_INVDIR) != 0, PM_TRACE, true, pst);
+    const bool packets = use_packets(c, p, dc);
+    int rc;
+    if (packets && (rc = launch_k_primary_pipelined(c, dc, a, slot, pst)) != RT_OK) return rc;
+    launch_k_paths(c, dc, a, false, (p->flags & RT_FLAG_FIX_INVDIR) != 0, packets ? PM_QUEUE : PM_TRACE, true, pst);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->lane_done[slot], pst));
     c->ahead.unjoined |= 1u << slot;
@@ -716,7 +838,7 @@ static int frame_call(rt_context* c, const DCamera& dc, const rt_params* p, uint
     if (!ah.valid) {
         const uint32_t k = cap;
         if (k < 2u) return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, prev, out, true);
-        if ((rc = ensure_paths_buffers(c, pixels)) != RT_OK) return rc;
+        if ((rc = ensure_paths_buffers(c, p->width, p->height)) != RT_OK) return rc;
         ah.base = frame_count;
         ah.count = k;
         ah.slot = c->lane_next++ % RT_LANES;
@@ -802,7 +924,8 @@ int rt_create(int device_id, rt_context** out_ctx) {
     // packet whose signal has not fired is such a packet: the kernel everybody waits for is never dispatched.  A process
     // with RCCL collectives hung that way on the GPU box with lowest-priority lanes, so the priority is not configurable.
     for (int k = 0; k < RT_LANES; k++) {
-        if ((e = hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking)) != hipSuccess ||
+        if ((e = hipEventCreateWithFlags(&c->prim_done[k], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->lane_done[k], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming)) != hipSuccess) {
             int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
@@ -824,6 +947,10 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_FRAME_BLOCKS")) c->tune_frame_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_FRAME_CHUNK")) c->tune_frame_chunk = atoi(e);
     if (const char* e = getenv("RT_TUNE_PACKETS")) c->tune_packets = atoi(e);
+    if (const char* e = getenv("RT_TUNE_BATCH_BLOCKS")) c->tune_batch_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_OVERLAP")) c->tune_overlap = atoi(e);
+    if (const char* e = getenv("RT_TUNE_STAGGER")) c->tune_stagger = atoi(e);
+    if (const char* e = getenv("RT_TUNE_QUEUE_BLOCKS")) c->tune_queue_blocks = atoi(e);
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
@@ -831,11 +958,13 @@ int rt_create(int device_id, rt_context** out_ctx) {
     // traverse while some wait for a refill would send the wave back and forth without progress
     auto clamp = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     c->tune_ahead = clamp(c->tune_ahead, 0, PT_MAX_BATCH);
-    c->tune_min_trav = clamp(c->tune_min_trav, 1, 48);
-    c->tune_min_service = clamp(c->tune_min_service, 1, 64);
+    c->tune_min_trav = clamp(c->tune_min_trav, 0, 48);       // 0: by the kind of launch
+    c->tune_min_service = clamp(c->tune_min_service, 0, 64);
     c->tune_w_inner = clamp(c->tune_w_inner, 1, 64);
     c->tune_w_leaf = clamp(c->tune_w_leaf, 1, 64);
     c->tune_frame_blocks = clamp(c->tune_frame_blocks, 1, PT_BLOCKS_PER_CU);
+    c->tune_batch_blocks = clamp(c->tune_batch_blocks, 1, PT_BLOCKS_PER_CU);
+    c->tune_queue_blocks = clamp(c->tune_queue_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
 #endif
     hipDeviceProp_t prop;
@@ -855,6 +984,7 @@ int rt_destroy(rt_context* c) {
             (void)hipStreamDestroy(c->lane_stream[k]);
         }
         if (c->lane_done[k]) (void)hipEventDestroy(c->lane_done[k]);
+        if (c->prim_done[k]) (void)hipEventDestroy(c->prim_done[k]);
         if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
     }
     free_scene(c);

@@ -1,0 +1,469 @@
+// Primary rays traced wave-wide: the 64 primary rays of an 8x8-pixel tile walk the BVH as ONE packet.
+//
+// The lanes of the path kernel (rt_paths.h) each follow their own ray: own node reference, own stack in LDS, own
+// 64-byte record fetch per visit.  The primary rays of a tile are neighbours, though: they leave one point and visit
+// nearly the same nodes (dragon80k at 1080p: 15 node visits per ray, 26 for the union over a tile).  k_primary gives a
+// tile to a wave, keeps the node reference and the stack in scalar registers, fetches every record ONCE per wave through
+// the scalar cache, and every lane tests its own ray against the shared boxes and triangles under a lane mask.
+//
+// Every lane sees exactly the node sequence the reference's traversal (raytrace.glsl:127-195) gives its ray:
+//   * a lane takes part in a node only if it would have visited it: its own distance to the child box is below its own
+//     closest hit when the node is entered (raytrace.glsl:174-189) and again when it is taken off the stack (:151);
+//   * the reference visits the nearer child first (equal distances: child 2).  The wave goes to the child that most of
+//     the lanes wanting BOTH children prefer; the lanes that prefer the other order skip it, take the second child with
+//     everybody else and come back for the first one afterwards (an extra stack entry that names only them).
+// Per lane the order of triangle tests, the strict `<` updates and every cull are therefore the reference's, and so are
+// the closest hit, ties included, and the work counters.
+//
+// Output per work item (tile, frame):
+//   hcount[item]        number of lanes whose ray hit something; PK_TRACE_ITEM if the packet gave up (stack deeper than
+//                       PK_STACK entries) -- the path kernel then traces that tile's primary rays lane by lane
+//   hitq[item*64 + k]   (t, triangle id, lane, 0) of the k-th hit lane: where the path kernel picks up the path
+//   samples[frame][pixel] = (1, 1, 1, dir.y) for every ray that left the scene: a finished path (raytrace.glsl:263-266)
+#ifndef RT_PACKETS_H
+#define RT_PACKETS_H
+
+#include "rt_paths.h"
+
+#define PK_BLOCK 256                 // 4 waves per workgroup
+#define PK_BLOCKS_PER_CU 8           // 32 waves per CU, 8 per SIMD (needs <= 64 VGPRs and 20 KiB of LDS per workgroup)
+#define PK_STACK 19                  // packet-stack entries (a 256-byte row of per-lane distances each, in LDS)
+#define PK_TRACE_ITEM 0xffffffffu
+
+typedef float pk_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) pk_f4* pk_cf4;   // constant address space: uniform addresses load through the scalar cache
+
+
+// The packet's whole traversal, hand-written: the step is bound by the scalar unit (one scalar instruction per four cycles
+// and SIMD), and the compiler's version of the ordering and stack logic took ~125 scalar and branch instructions per node
+// where ~30 do.  Same algorithm, statement for statement, as the loop in k_primary<true> below (which the counting build
+// keeps): EXEC is the set of lanes taking part in the current node, the node reference, the stack pointer and the lane
+// masks live in SGPRs, the packet's stack in three VGPRs (lane i = entry i, v_writelane / v_readlane) plus one LDS row of
+// per-lane distances per entry.  The slab test, the triangle test (with the correctly rounded division) and their
+// instruction order are the compiler's own output for box_dist / tri_dist_flat, so results are bit-identical.
+// Registers s36-s91 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
+__device__ __forceinline__ bool pk_traverse(unsigned long long nodes, unsigned long long tris, int root, unsigned long long in0,
+                                            rt_vec3 o, rt_vec3 d, rt_vec3 inv, uint32_t lrow, float& best, int& best_id) {
+    int gave;
+    asm volatile(
+        "s_mov_b64 s[74:75], exec\n\t"
+        "s_mov_b32 s90, 0x38d1b717\n\t"            // RT_EPS
+        "v_mov_b32_e32 v60, 0x7f800000\n\t"        // +inf
+        "s_mov_b32 s71, 0\n\t"                     // stack pointer
+        "s_mov_b32 %[gave], 0\n\t"
+        "s_mov_b32 s70, %[root]\n\t"               // current node
+        "s_and_b64 exec, s[74:75], %[in0]\n\t"
+        "s_cbranch_execz Ldone%=\n"
+        "Lnode%=:\n\t"
+        "s_cmp_lt_i32 s70, 0\n\t"
+        "s_cbranch_scc1 Lleaf%=\n\t"
+        // ---- inner node: record = (c1.min c1.max c2.min c2.max ref1 ref2 - -)
+        "s_lshl_b32 s72, s70, 6\n\t"
+        "s_load_dwordx16 s[36:51], %[nodes], s72\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32_e32 v40, s36, %[ox]\n\t"
+        "v_sub_f32_e32 v41, s37, %[oy]\n\t"
+        "v_sub_f32_e32 v42, s38, %[oz]\n\t"
+        "v_sub_f32_e32 v43, s39, %[ox]\n\t"
+        "v_sub_f32_e32 v44, s40, %[oy]\n\t"
+        "v_sub_f32_e32 v45, s41, %[oz]\n\t"
+        "v_mul_f32_e32 v40, %[ix], v40\n\t"
+        "v_mul_f32_e32 v41, %[iy], v41\n\t"
+        "v_mul_f32_e32 v42, %[iz], v42\n\t"
+        "v_mul_f32_e32 v43, %[ix], v43\n\t"
+        "v_mul_f32_e32 v44, %[iy], v44\n\t"
+        "v_mul_f32_e32 v45, %[iz], v45\n\t"
+        "v_min_f32_e32 v46, v40, v43\n\t"
+        "v_min_f32_e32 v47, v41, v44\n\t"
+        "v_min_f32_e32 v48, v42, v45\n\t"
+        "v_max_f32_e32 v40, v40, v43\n\t"
+        "v_max_f32_e32 v41, v41, v44\n\t"
+        "v_max_f32_e32 v42, v42, v45\n\t"
+        "v_max3_f32 v49, v46, v47, v48\n\t"        // tNear
+        "v_min3_f32 v50, v40, v41, v42\n\t"        // tFar
+        "v_sub_f32_e32 v40, s42, %[ox]\n\t"
+        "v_sub_f32_e32 v41, s43, %[oy]\n\t"
+        "v_sub_f32_e32 v42, s44, %[oz]\n\t"
+        "v_sub_f32_e32 v43, s45, %[ox]\n\t"
+        "v_sub_f32_e32 v44, s46, %[oy]\n\t"
+        "v_sub_f32_e32 v45, s47, %[oz]\n\t"
+        "v_cmp_lt_f32_e64 s[80:81], s90, v49\n\t"  // EPS < tNear
+        "v_mul_f32_e32 v40, %[ix], v40\n\t"
+        "v_mul_f32_e32 v41, %[iy], v41\n\t"
+        "v_mul_f32_e32 v42, %[iz], v42\n\t"
+        "v_mul_f32_e32 v43, %[ix], v43\n\t"
+        "v_mul_f32_e32 v44, %[iy], v44\n\t"
+        "v_mul_f32_e32 v45, %[iz], v45\n\t"
+        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"       // tFar >= tNear
+        "v_cmp_lt_f32_e64 s[78:79], s90, v50\n\t"  // EPS < tFar
+        "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"
+        "v_min_f32_e32 v46, v40, v43\n\t"
+        "v_min_f32_e32 v47, v41, v44\n\t"
+        "v_min_f32_e32 v48, v42, v45\n\t"
+        "v_max_f32_e32 v40, v40, v43\n\t"
+        "v_max_f32_e32 v41, v41, v44\n\t"
+        "v_max_f32_e32 v42, v42, v45\n\t"
+        "s_and_b64 vcc, vcc, s[78:79]\n\t"
+        "v_max3_f32 v49, v46, v47, v48\n\t"
+        "v_min3_f32 v50, v40, v41, v42\n\t"
+        "v_cndmask_b32_e32 v51, v60, v51, vcc\n\t"  // d1 = hit ? (tNear > EPS ? tNear : 0) : inf
+        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"
+        "v_cmp_lt_f32_e64 s[78:79], s90, v50\n\t"
+        "v_cmp_lt_f32_e64 s[80:81], s90, v49\n\t"
+        "s_and_b64 vcc, vcc, s[78:79]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 v52, 0, v49, s[80:81]\n\t"
+        "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t"  // d2
+        // who wants which child, and in which order (raytrace.glsl:173-190)
+        "v_cmp_lt_f32_e64 s[52:53], v51, %[best]\n\t"   // W1
+        "v_cmp_lt_f32_e64 s[54:55], v52, %[best]\n\t"   // W2
+        "v_cmp_lt_f32_e64 s[56:57], v51, v52\n\t"       // LT: child 1 first
+        "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t"    // both
+        "s_and_b64 s[60:61], s[58:59], s[56:57]\n\t"    // both, child 1 first
+        "s_andn2_b64 s[62:63], s[58:59], s[56:57]\n\t"  // both, child 2 first
+        "s_bcnt1_i32_b64 s72, s[60:61]\n\t"
+        "s_bcnt1_i32_b64 s73, s[62:63]\n\t"
+        "s_cmp_gt_u32 s72, s73\n\t"                     // scc: the wave takes child 1 first
+        "s_cselect_b64 s[64:65], s[52:53], s[54:55]\n\t"  // lanes of the first child
+        "s_cselect_b64 s[66:67], s[54:55], s[52:53]\n\t"  // lanes of the second child
+        "s_cselect_b32 s68, s48, s49\n\t"               // first child
+        "s_cselect_b32 s69, s49, s48\n\t"               // second child
+        "s_cselect_b64 s[62:63], s[62:63], s[60:61]\n\t"  // dissenters
+        "s_cselect_b64 vcc, -1, 0\n\t"
+        "v_cndmask_b32_e32 v53, v52, v51, vcc\n\t"      // distances to the first ...
+        "v_cndmask_b32_e32 v54, v51, v52, vcc\n\t"      // ... and to the second child
+        "s_andn2_b64 s[64:65], s[64:65], s[62:63]\n\t"
+        "s_cbranch_scc0 Lswap%=\n\t"
+        "s_cmp_gt_u32 s71, %[room]\n\t"
+        "s_cbranch_scc1 Lgiveup%=\n\t"
+        "s_cmp_eq_u64 s[62:63], 0\n\t"
+        "s_cbranch_scc1 Lnodis%=\n\t"
+        "s_mov_b32 m0, s71\n\t"                          // the dissenters come back for the first child after the second
+        "s_nop 0\n\t"
+        "v_writelane_b32 v57, s68, m0\n\t"
+        "v_writelane_b32 v58, s62, m0\n\t"
+        "v_writelane_b32 v59, s63, m0\n\t"
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"
+        "ds_write_b32 v55, v53\n\t"
+        "s_add_i32 s71, s71, 1\n"
+        "Lnodis%=:\n\t"
+        "s_cmp_eq_u64 s[66:67], 0\n\t"
+        "s_cbranch_scc1 Lgo%=\n\t"
+        "s_mov_b32 m0, s71\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 v57, s69, m0\n\t"
+        "v_writelane_b32 v58, s66, m0\n\t"
+        "v_writelane_b32 v59, s67, m0\n\t"
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"
+        "ds_write_b32 v55, v54\n\t"
+        "s_add_i32 s71, s71, 1\n"
+        "Lgo%=:\n\t"
+        "s_mov_b32 s70, s68\n\t"
+        "s_mov_b64 exec, s[64:65]\n\t"
+        "s_branch Lnode%=\n"
+        "Lswap%=:\n\t"                                    // nobody enters the first child (then nobody dissents): on to the second
+        "s_cmp_eq_u64 s[66:67], 0\n\t"
+        "s_cbranch_scc1 Lpop%=\n\t"
+        "s_mov_b32 s70, s69\n\t"
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "s_branch Lnode%=\n"
+        // ---- leaf: triangle records (a flags)(e1 id)(e2 -), the last one of the leaf has flag bit 0
+        "Lleaf%=:\n\t"
+        "s_cmp_eq_u32 s70, 0x80000001\n\t"
+        "s_cbranch_scc1 Lpop%=\n\t"
+        "s_not_b32 s72, s70\n\t"
+        "s_lshl_b32 s72, s72, 6\n"
+        "Ltri%=:\n\t"
+        "s_load_dwordx8 s[36:43], %[tris], s72\n\t"
+        "s_add_u32 s73, s72, 32\n\t"
+        "s_load_dwordx4 s[44:47], %[tris], s73\n\t"
+        "s_add_u32 s72, s72, 64\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f32_e32 v40, s46, %[dy]\n\t"
+        "v_mul_f32_e32 v41, s45, %[dz]\n\t"
+        "v_mul_f32_e32 v42, s44, %[dz]\n\t"
+        "v_mul_f32_e32 v43, s46, %[dx]\n\t"
+        "v_mul_f32_e32 v44, s45, %[dx]\n\t"
+        "v_mul_f32_e32 v45, s44, %[dy]\n\t"
+        "v_sub_f32_e32 v40, v40, v41\n\t"               // p = cross(d, e2)
+        "v_sub_f32_e32 v41, v42, v43\n\t"
+        "v_sub_f32_e32 v42, v44, v45\n\t"
+        "v_subrev_f32_e32 v43, s36, %[ox]\n\t"          // s = o - a
+        "v_subrev_f32_e32 v44, s37, %[oy]\n\t"
+        "v_subrev_f32_e32 v45, s38, %[oz]\n\t"
+        "v_mul_f32_e32 v46, s40, v40\n\t"
+        "v_mul_f32_e32 v47, s41, v41\n\t"
+        "v_mul_f32_e32 v48, s42, v42\n\t"
+        "v_mul_f32_e32 v40, v43, v40\n\t"
+        "v_mul_f32_e32 v41, v44, v41\n\t"
+        "v_mul_f32_e32 v42, v45, v42\n\t"
+        "v_mul_f32_e32 v49, s42, v44\n\t"
+        "v_mul_f32_e32 v50, s41, v45\n\t"
+        "v_mul_f32_e32 v45, s40, v45\n\t"
+        "v_mul_f32_e32 v51, s42, v43\n\t"
+        "v_mul_f32_e32 v43, s41, v43\n\t"
+        "v_mul_f32_e32 v44, s40, v44\n\t"
+        "v_add_f32_e32 v46, v46, v47\n\t"
+        "v_add_f32_e32 v40, v40, v41\n\t"
+        "v_sub_f32_e32 v41, v49, v50\n\t"               // q = cross(s, e1)
+        "v_sub_f32_e32 v45, v45, v51\n\t"
+        "v_sub_f32_e32 v43, v43, v44\n\t"
+        "v_add_f32_e32 v44, v48, v46\n\t"               // det = dot(e1, p)
+        "v_add_f32_e32 v40, v42, v40\n\t"               // dot(s, p)
+        "v_mul_f32_e32 v42, %[dx], v41\n\t"
+        "v_mul_f32_e32 v46, %[dy], v45\n\t"
+        "v_mul_f32_e32 v41, s44, v41\n\t"
+        "v_mul_f32_e32 v45, s45, v45\n\t"
+        "v_div_scale_f32 v48, s[78:79], v44, v44, 1.0\n\t"   // inv_det = 1 / det, correctly rounded
+        "v_add_f32_e32 v41, v41, v45\n\t"
+        "v_rcp_f32_e32 v45, v48\n\t"
+        "v_mul_f32_e32 v47, %[dz], v43\n\t"
+        "v_mul_f32_e32 v43, s46, v43\n\t"
+        "v_add_f32_e32 v41, v43, v41\n\t"               // dot(e2, q)
+        "v_fma_f32 v43, -v48, v45, 1.0\n\t"
+        "v_div_scale_f32 v49, vcc, 1.0, v44, 1.0\n\t"
+        "v_fmac_f32_e32 v45, v43, v45\n\t"
+        "v_mul_f32_e32 v43, v49, v45\n\t"
+        "v_add_f32_e32 v42, v42, v46\n\t"
+        "v_fma_f32 v46, -v48, v43, v49\n\t"
+        "v_fmac_f32_e32 v43, v46, v45\n\t"
+        "v_fma_f32 v46, -v48, v43, v49\n\t"
+        "v_div_fmas_f32 v43, v46, v45, v43\n\t"
+        "v_div_fixup_f32 v43, v43, v44, 1.0\n\t"
+        "v_add_f32_e32 v42, v47, v42\n\t"               // dot(d, q)
+        "v_mul_f32_e32 v40, v40, v43\n\t"               // u
+        "s_and_b32 s91, s39, 1\n\t"
+        "v_mul_f32_e32 v42, v42, v43\n\t"               // v
+        "v_mul_f32_e32 v41, v41, v43\n\t"               // t
+        "v_cmp_gt_f32_e32 vcc, 0, v40\n\t"
+        "v_cmp_gt_f32_e64 s[80:81], |v40|, s90\n\t"
+        "v_add_f32_e32 v43, -1.0, v40\n\t"
+        "v_mov_b32_e32 v61, s43\n\t"
+        "v_cmp_lt_f32_e64 s[82:83], |v44|, s90\n\t"
+        "v_cmp_lt_f32_e64 s[84:85], 1.0, v40\n\t"
+        "v_add_f32_e32 v40, v40, v42\n\t"
+        "s_and_b64 s[80:81], vcc, s[80:81]\n\t"
+        "v_cmp_gt_f32_e64 s[86:87], |v43|, s90\n\t"
+        "v_cmp_gt_f32_e64 s[88:89], 0, v42\n\t"
+        "v_cmp_gt_f32_e64 s[52:53], |v42|, s90\n\t"
+        "v_cmp_lt_f32_e32 vcc, 1.0, v40\n\t"
+        "v_add_f32_e32 v40, -1.0, v40\n\t"
+        "s_or_b64 s[82:83], s[82:83], s[80:81]\n\t"
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "s_and_b64 s[88:89], s[88:89], s[52:53]\n\t"
+        "v_cmp_gt_f32_e64 s[80:81], |v40|, s90\n\t"
+        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"
+        "s_and_b64 s[82:83], vcc, s[80:81]\n\t"
+        "s_or_b64 s[84:85], s[88:89], s[84:85]\n\t"
+        "v_cmp_nlt_f32_e64 s[54:55], s90, v41\n\t"
+        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"
+        "s_or_b64 vcc, s[54:55], s[84:85]\n\t"
+        "v_cndmask_b32_e32 v40, v41, v60, vcc\n\t"      // rejected ? inf : t
+        "v_cmp_lt_f32_e32 vcc, v40, %[best]\n\t"
+        "s_cmp_eq_u32 s91, 0\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[bid], %[bid], v61, vcc\n\t"
+        "v_cndmask_b32_e32 %[best], %[best], v40, vcc\n\t"
+        "s_cbranch_scc1 Ltri%=\n"
+        // ---- next stack entry that still has a lane whose distance to it is below its closest hit (raytrace.glsl:151)
+        "Lpop%=:\n\t"
+        "s_cmp_eq_u32 s71, 0\n\t"
+        "s_cbranch_scc1 Ldone%=\n\t"
+        "s_add_i32 s71, s71, -1\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 s78, v58, s71\n\t"
+        "v_readlane_b32 s79, v59, s71\n\t"
+        "s_mov_b64 exec, s[78:79]\n\t"
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"
+        "ds_read_b32 v56, v55\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_lt_f32_e32 vcc, v56, %[best]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_scc0 Lpop%=\n\t"
+        "v_readlane_b32 s70, v57, s71\n\t"
+        "s_branch Lnode%=\n"
+        "Lgiveup%=:\n\t"
+        "s_mov_b32 %[gave], 1\n"
+        "Ldone%=:\n\t"
+        "s_mov_b64 exec, s[74:75]"
+        : [gave] "=&s"(gave), [best] "+v"(best), [bid] "+v"(best_id)
+        : [nodes] "s"(nodes), [tris] "s"(tris), [root] "s"(root), [in0] "s"(in0), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
+          [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [lrow] "v"(lrow),
+          [room] "n"(PK_STACK - 2)
+        : "memory", "vcc", "scc", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+          "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88",
+          "s89", "s90", "s91", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+          "v56", "v57", "v58", "v59", "v60", "v61");
+    return gave != 0;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene sc, DCamera cam, PathsArgs a) {
+    __shared__ float s_dist[PK_BLOCK / 64][PK_STACK][64];
+    __shared__ uint32_t s_next;
+    const int tid = threadIdx.x, lane = tid & 63;
+    float(*const dist_rows)[64] = s_dist[tid >> 6];
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    const pk_cf4 nodes = (pk_cf4)(uintptr_t)sc.nodes;
+    const pk_cf4 tris = (pk_cf4)(uintptr_t)sc.tris;
+    // same dealing of items to workgroups as in k_paths: every round of gridDim.x items is split into 8 runs, one per XCD
+    const uint32_t xcd_slot = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
+    Counters tot = {0, 0, 0, 0, 0};
+    unsigned long long tot_paths = 0;
+
+    // Persistent waves: launching one short-lived workgroup per four items instead (so that the hardware balances tiles of
+    // sky against tiles on the object) measured 2 % (dragon80k) to 8 % (teapot) slower end to end.
+    for (;;) {
+        uint32_t k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        const uint32_t item = xcd_slot + k * gridDim.x;
+        if (item >= a.total_tiles) break;
+        uint32_t f;
+        int gx, gy;
+        item_pixel(a, item, lane, f, gx, gy);
+        const bool valid = gx < cam.width && gy < cam.height;
+        rt_vec3 o, d, inv;
+        primary_ray(cam, gx, gy, o, d, inv);
+        float best = RT_INF;
+        int best_id = -1;
+        Counters cn = {0, 0, 0, 0, 0};
+        const float d0 = box_dist(o, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2]);
+        bool in = valid && d0 != RT_INF;   // does this lane take part in the current node?
+        if (COUNT && valid) {
+            cn.rays++;
+            cn.box += in ? 2u : 1u;   // the reference evaluates the root box a second time to seed its stack
+        }
+        int cur = __builtin_amdgcn_ballot_w64(in) != 0ull ? sc.root_ref : RT_REF_IDLE;
+        if (COUNT && in && cur < 0) cn.pops++;
+        int sp = 0;
+        int stk_ref = 0, stk_lo = 0, stk_hi = 0;   // lane i of these registers = entry i of the packet's stack
+#define PK_PUSH(ref_, mask_)                                                     \
+    do {                                                                         \
+        const bool top_ = lane == sp;                                            \
+        stk_ref = top_ ? (ref_) : stk_ref;                                       \
+        stk_lo = top_ ? (int)(uint32_t)(mask_) : stk_lo;                         \
+        stk_hi = top_ ? (int)(uint32_t)((mask_) >> 32) : stk_hi;                 \
+    } while (0)
+        bool gave_up = false;
+
+        if (!COUNT) {   // the hand-written loop; the counting build keeps the C++ one below
+            const uint32_t lrow = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)&dist_rows[0][lane];
+            gave_up = pk_traverse((unsigned long long)(uintptr_t)sc.nodes, (unsigned long long)(uintptr_t)sc.tris, sc.root_ref,
+                                  __builtin_amdgcn_ballot_w64(in), o, d, inv, lrow, best, best_id);
+            cur = RT_REF_IDLE;
+        }
+#ifdef PK_DEBUG
+        uint32_t steps = 0;
+#endif
+        while (cur != RT_REF_IDLE) {
+#ifdef PK_DEBUG
+            if (++steps > 100000u) {
+                if (lane == 0) printf("k_primary: item %u stuck at node %d sp %d\n", item, cur, sp);
+                gave_up = true;
+                break;
+            }
+#endif
+            if (cur >= 0) {
+                const pk_f4 q0 = nodes[(uint32_t)cur * 4u], q1 = nodes[(uint32_t)cur * 4u + 1u], q2 = nodes[(uint32_t)cur * 4u + 2u],
+                            q3 = nodes[(uint32_t)cur * 4u + 3u];
+                const int r1 = (int)rt_f2u(q3.x), r2 = (int)rt_f2u(q3.y);
+                const float d1 = box_dist(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                const float d2 = box_dist(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                if (COUNT && in) {
+                    cn.pops++;
+                    cn.box += 2;
+                }
+                const bool w1 = in && d1 < best, w2 = in && d2 < best, lt = d1 < d2;
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(w1), m2 = __builtin_amdgcn_ballot_w64(w2);
+                const unsigned long long mlt = __builtin_amdgcn_ballot_w64(lt);
+                const unsigned long long both = m1 & m2;
+                // the child most of the lanes that want both would visit first (ties: child 2, as a single ray does)
+                const int n1 = __builtin_popcountll(both & mlt), n2 = __builtin_popcountll(both & ~mlt);
+                const bool first1 = n1 > n2;
+                const unsigned long long dissent = both & (first1 ? ~mlt : mlt);
+                unsigned long long mf = (first1 ? m1 : m2) & ~dissent, ms = first1 ? m2 : m1;
+                int rf = first1 ? r1 : r2, rs = first1 ? r2 : r1;
+                float df = first1 ? d1 : d2, ds = first1 ? d2 : d1;
+                if (mf == 0ull) {   // nobody enters the first child now (then nobody dissents either): straight on to the second
+                    mf = ms, rf = rs, df = ds;
+                    ms = 0ull;
+                }
+                if ((dissent != 0ull ? 1 : 0) + (ms != 0ull ? 1 : 0) + sp > PK_STACK) {
+                    gave_up = true;
+                    break;
+                }
+                if (dissent != 0ull) {   // they come back for the first child after the second
+                    PK_PUSH(rf, dissent);
+                    dist_rows[sp][lane] = df;
+                    sp++;
+                }
+                if (ms != 0ull) {
+                    PK_PUSH(rs, ms);
+                    dist_rows[sp][lane] = ds;
+                    sp++;
+                }
+                if (mf != 0ull) {
+                    cur = rf;
+                    in = (((uint32_t)mf & bit_lo) | ((uint32_t)(mf >> 32) & bit_hi)) != 0u;
+                    if (COUNT && in && cur < 0) cn.pops++;
+                    continue;
+                }
+            } else if (cur != RT_REF_EMPTY) {
+                uint32_t t = (uint32_t)~cur;
+                for (;;) {
+#ifdef PK_DEBUG
+                    if (++steps > 100000u) {
+                        if (lane == 0) printf("k_primary: item %u stuck in leaf %u\n", item, t);
+                        break;
+                    }
+#endif
+                    const pk_f4 t0 = tris[t * 4u], t1 = tris[t * 4u + 1u], t2 = tris[t * 4u + 2u];
+                    const float dist = tri_dist_flat(o, d, rt_v3(t0.x, t0.y, t0.z), rt_v3(t1.x, t1.y, t1.z), rt_v3(t2.x, t2.y, t2.z));
+                    if (COUNT && in) cn.tri++;
+                    if (in && dist < best) {
+                        best = dist;
+                        best_id = (int)rt_f2u(t1.w);
+                    }
+                    if (rt_f2u(t0.w) & 1u) break;
+                    t++;
+                }
+            }
+            // next entry of the stack that still has a lane whose distance to it is below its closest hit (raytrace.glsl:151)
+            cur = RT_REF_IDLE;
+            while (sp > 0) {
+                sp--;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(stk_lo, sp), hi = (uint32_t)__builtin_amdgcn_readlane(stk_hi, sp);
+                const float dd = dist_rows[sp][lane];
+                in = ((lo & bit_lo) | (hi & bit_hi)) != 0u && dd < best;
+                if (__builtin_amdgcn_ballot_w64(in) != 0ull) {
+                    cur = __builtin_amdgcn_readlane(stk_ref, sp);
+                    if (COUNT && in && cur < 0) cn.pops++;
+                    break;
+                }
+            }
+        }
+
+#undef PK_PUSH
+        // Every lane takes the same way from here to the next item: all lanes store the item's count (same address, same
+        // value) rather than one of them under a branch, so that no lane reaches the next grab ahead of the others.
+        const bool hit = !gave_up && valid && best < RT_INF;
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+        // a packet that gave up stores nothing and counts nothing: the path kernel traces the tile's rays lane by lane
+        if (hit) a.hitq[(size_t)item * 64u + rank] = make_float4(best, rt_u2f((uint32_t)best_id), rt_u2f((uint32_t)lane), 0.0f);
+        if (!gave_up && valid && !hit)
+            a.samples[(size_t)f * a.pixels + ((uint32_t)gy * (uint32_t)cam.width + (uint32_t)gx)] = make_float4(1.0f, 1.0f, 1.0f, d.y);
+        a.hcount[item] = gave_up ? PK_TRACE_ITEM : (uint32_t)__builtin_popcountll(hm);
+        if (COUNT && !gave_up) {
+            tot.box += cn.box, tot.tri += cn.tri, tot.rays += cn.rays, tot.pops += cn.pops;
+            tot_paths += valid ? 1ull : 0ull;
+        }
+    }
+    if (COUNT && a.counters) flush_counters6(tot, tot_paths, a.counters);
+}
+
+#endif  // RT_PACKETS_H

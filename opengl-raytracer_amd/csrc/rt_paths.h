@@ -56,8 +56,10 @@ static_assert(PT_SLOT_SHIFT > 0 && (1 << PT_SLOT_SHIFT) == PT_BLOCK * 8, "PT_BLO
 #define PT_W_INNER 1           // step choice: inner-node visit when PT_W_INNER * (lanes at inner nodes) >=
 #define PT_W_LEAF 3            //              PT_W_LEAF * (lanes at leaves), triangle test otherwise (a triangle step is the
                                //              cheaper one and frees its lanes for the next inner steps)
+#ifndef PT_MAX_BATCH
 #define PT_MAX_BATCH 16        // frames per launch.  The end of a launch drains slowly (a few long paths keep their waves
                                // alive, ~0.3 ms on dragon80k); consecutive launches of a call overlap on two streams to hide it
+#endif
 #define PT_STRIP_W 16          // tile columns per vertical strip of the tile numbering (the last strip may stick out of the image)
 #define PT_STRIPE_TILES 2      // interleaved bands: a stripe is 2 tile rows = 16 pixel rows
 
@@ -68,7 +70,9 @@ enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
 //   PM_TRACE    every path traces its primary ray (what the reference does; the default)
 //   PM_PRIMARY  one pass over the image that traces only the primary rays and stores their closest hits
 //   PM_REUSE    every path starts from the stored hit of its pixel and traces only its bounce rays (RT_FLAG_REUSE_PRIMARY)
-enum { PM_TRACE = 0, PM_PRIMARY = 1, PM_REUSE = 2 };
+//   PM_QUEUE    the primary rays of the launch have been traced tile by tile by k_primary (rt_packets.h): every path
+//               starts from the hit that kernel queued for it; paths whose primary ray left the scene are already finished
+enum { PM_TRACE = 0, PM_PRIMARY = 1, PM_REUSE = 2, PM_QUEUE = 3 };
 
 struct PathsArgs {
     uint32_t frame_base, frame_stride, num_frames;
@@ -86,11 +90,29 @@ struct PathsArgs {
     float cull_slack, cull_slope;   // true-direction cull of the inner-node step: slack < 0 off; else a box is widened by the pad
                                     // (cull_slack + cull_slope * reach of the box from the ray origin) / 2
     float2* hits;                   // [pixels] closest hit of every pixel's primary ray, (t, id bits): written in PM_PRIMARY, read in PM_REUSE
+    float4* hitq;                   // [total_tiles][64] PM_QUEUE: (t, id bits, lane bits, 0) of the k-th primary ray of the item that hit something
+    uint32_t* hcount;               // [total_tiles] PM_QUEUE: how many did; 0xffffffff: the item's primary rays are still to be traced, lane by lane
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
     size_t spill_stride;
     unsigned long long* counters;
 };
+
+// Pixel (gx, gy) of position l (0..63) of work item `item`, and the item's frame index f within the launch.
+// The frames of a launch share the camera: tile t of every frame is numbered before tile t+1 of any, so the waves that run
+// at one time walk the same part of the BVH.  Tiles are numbered strip by strip (PT_STRIP_W tile columns wide, row-major
+// inside), so that the tiles the chip works on at one time form a compact block of the image, not a full-width band.
+__device__ __forceinline__ void item_pixel(const PathsArgs& a, uint32_t item, int l, uint32_t& f, int& gx, int& gy) {
+    const uint32_t tq = item / a.num_frames;
+    f = item - tq * a.num_frames;
+    const int t = (int)tq;
+    const int strip = t / a.strip_tiles, r = t - strip * a.strip_tiles;
+    const int ty = r / PT_STRIP_W, tx = strip * PT_STRIP_W + r % PT_STRIP_W;
+    // tile row of the band -> tile row of the image
+    const int gty = a.stripe_period ? (ty / PT_STRIPE_TILES) * a.stripe_period + (ty % PT_STRIPE_TILES) + a.tile_y0 : ty + a.tile_y0;
+    gx = tx * 8 + (l & 7);
+    gy = gty * 8 + (l >> 3);
+}
 
 __device__ __forceinline__ void flush_counters6(const Counters& cn, unsigned long long paths, unsigned long long* g) {
     unsigned long long v[6] = {cn.box, cn.tri, cn.rays, cn.hits, cn.pops, paths};
@@ -272,7 +294,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     const uint32_t xcd_slot = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     // wave-uniform cursor into the tile pool
     uint32_t tile_g = 0;
-    int tile_off = 64;
+    int tile_off = 64, tile_cnt = 64;   // positions handed out / to hand out of the current item
+    bool tile_traced = false;           // PM_QUEUE: the current item's primary rays have been traced by k_primary
     bool exhausted = false;
 
     // lane state
@@ -294,9 +317,18 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
 #define DIAG(k_, v_)
 #endif
 
+#ifdef PK_DEBUG
+    uint32_t wd = 0;
+#endif
     for (;;) {
         // ------------------------------------------------------------------ service phase
         for (;;) {
+#ifdef PK_DEBUG
+            if (++wd > 2000000u) {
+                if ((tid & 63) == 0) printf("k_paths<%d>: wg %d stuck in service: tile_g %u off %d cnt %d exhausted %d state %d\n", PMODE, (int)blockIdx.x, tile_g, tile_off, tile_cnt, (int)exhausted, state);
+                return;
+            }
+#endif
             DIAG(4, 1);
             if (state == ST_DONE || (state == ST_NEED && !exhausted)) { DIAG(5, 1); }
             if (PMODE == PM_PRIMARY) {
@@ -326,32 +358,38 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
             }
             const unsigned long long need = __builtin_amdgcn_ballot_w64(state == ST_NEED);
             if (need != 0ull && !exhausted) {
-                if (tile_off >= 64) {
+                // PM_QUEUE: an item holds the tile_cnt primary rays of its tile that hit something (none: the next item)
+                while (tile_off >= tile_cnt) {
                     uint32_t k = 0;
                     if ((tid & 63) == 0) k = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                     tile_g = a.chunk == 1u ? xcd_slot + k * gridDim.x : ((k / a.chunk) * gridDim.x + xcd_slot) * a.chunk + k % a.chunk;
                     tile_off = 0;
-                    if (tile_g >= a.total_tiles) exhausted = true;
+                    if (tile_g >= a.total_tiles) {
+                        exhausted = true;
+                        break;
+                    }
+                    if (PMODE == PM_QUEUE) {
+                        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.hcount[tile_g]);
+                        tile_traced = n != 0xffffffffu;
+                        tile_cnt = tile_traced ? (int)n : 64;
+                    }
                 }
                 if (!exhausted) {
                     int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                    int avail = 64 - tile_off;
+                    int avail = tile_cnt - tile_off;
                     if (state == ST_NEED && rank < avail) {
                         int l = tile_off + rank;
-                        // the frames of a launch share the camera: tile t of every frame is handed out before tile t+1 of
-                        // any, so the waves that run at one time walk the same part of the BVH
-                        const uint32_t tq = tile_g / a.num_frames;
-                        const uint32_t f = tile_g - tq * a.num_frames;
-                        const int t = (int)tq;
-                        // tiles are numbered strip by strip (PT_STRIP_W tile columns wide, row-major inside), so that the
-                        // tiles the chip works on at one time form a compact block of the image, not a full-width band
-                        const int strip = t / a.strip_tiles, r = t - strip * a.strip_tiles;
-                        const int ty = r / PT_STRIP_W, tx = strip * PT_STRIP_W + r % PT_STRIP_W;
-                        // tile row of the band -> tile row of the image
-                        const int gty = a.stripe_period ? (ty / PT_STRIPE_TILES) * a.stripe_period + (ty % PT_STRIPE_TILES) + a.tile_y0
-                                                        : ty + a.tile_y0;
-                        int gx = tx * 8 + (l & 7), gy = gty * 8 + (l >> 3);
+                        if (PMODE == PM_QUEUE && tile_traced) {
+                            // the path starts where k_primary left it: at the closest hit of its primary ray
+                            const float4 h = a.hitq[(size_t)tile_g * 64u + (uint32_t)l];
+                            best = h.x;
+                            best_id = (int)rt_f2u(h.y);
+                            l = (int)rt_f2u(h.z);
+                        }
+                        uint32_t f;
+                        int gx, gy;
+                        item_pixel(a, tile_g, l, f, gx, gy);
                         if (gx < cam.width && gy < cam.height) {
                             primary_ray(cam, gx, gy, p.o, p.d, p.inv);
                             p.seed = pixel_seed(cam, gx, gy, a.frame_base + f * a.frame_stride);
@@ -366,10 +404,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                                 best_id = (int)rt_f2u(h.y);
                                 cur = RT_REF_IDLE;
                                 state = ST_DONE;
+                                if (COUNT) paths++;
+                            } else if (PMODE == PM_QUEUE && tile_traced) {
+                                cur = RT_REF_IDLE;
+                                state = ST_DONE;   // k_primary has counted the path and its primary ray
                             } else {
                                 state = ST_NEW;
+                                if (COUNT) paths++;
                             }
-                            if (COUNT) paths++;
                         }
                     }
                     int taken = __builtin_popcountll(need);
@@ -420,6 +462,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
         }                                                    \
     }
         for (;;) {
+#ifdef PK_DEBUG
+            if (++wd > 2000000u) {
+                if ((tid & 63) == 0) printf("k_paths<%d>: wg %d stuck in traversal\n", PMODE, (int)blockIdx.x);
+                return;
+            }
+#endif
             // idle lanes hold cur == RT_REF_IDLE (INT_MIN): inner <=> cur >= 0, leaf <=> cur in (INT_MIN, -1]
             const bool want_inner = cur >= 0;
             const bool want_leaf = (uint32_t)cur > 0x80000000u;

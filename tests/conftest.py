@@ -64,18 +64,29 @@ def rrmse(a: np.ndarray, b: np.ndarray) -> float:
 
 
 def render_both_ways(pkg, ctx, cam, params, want, cnt_o, start=None, nan_ok=False, what=""):
-    """Renders `params` three times and holds every image to the oracle's bit for bit: with work counters as asked, with
-    work counters and RT_FLAG_NO_CULL, and exactly as asked WITHOUT counters -- the instantiation a timed run executes (its
-    traversal steps end in hand-scheduled code that counting builds do not take).  The uncut render must also show the
-    oracle's six work counters exactly.  The default render may skip subtrees a bounce ray cannot reach: it must trace
-    the same rays, find the same hits and finish the same paths (counters 2, 3, 5) with no more box tests, triangle
-    tests and node visits (0, 1, 4) than the reference runs.  Returns the default counting render and its counters."""
+    """Renders `params` five times and holds every image to the oracle's bit for bit:
+      counted   with work counters, otherwise as asked
+      uncut     with work counters and RT_FLAG_NO_CULL: the reference's literal traversal, lane by lane
+      timed     exactly as asked, WITHOUT counters -- the instantiation a timed run executes (its traversal steps end in
+                hand-scheduled code that counting builds do not take)
+      packets / counted packets   as timed / counted with RT_FLAG_PACKETS: the primary rays of every tile traced as one packet
+                (hand-written loop / its C++ twin) and the paths continued from the hit queues, whether or not the
+                library's own estimate would have chosen that for this scene and image size
+    The uncut render must also show the oracle's six work counters exactly.  The other counting renders may skip subtrees a
+    bounce ray cannot reach: they must trace the same rays, find the same hits and finish the same paths (counters 2, 3, 5)
+    with no more box tests, triangle tests and node visits (0, 1, 4) than the reference runs.  Returns the default counting
+    render and its counters."""
     out = None
-    for variant in ("counted", "uncut", "timed"):
-        no_cull = variant == "uncut"
+    default_pipeline = not (params.flags & (pkg.RT_FLAG_MEGAKERNEL | pkg.RT_FLAG_WAVEFRONT))
+    variants = ("counted", "uncut", "timed") + (("packets", "counted packets") if default_pipeline else ())
+    for variant in variants:
         p = type(params).from_buffer_copy(params)
-        if variant != "timed":
-            p.flags |= pkg.RT_FLAG_COUNTERS | (pkg.RT_FLAG_NO_CULL if no_cull else 0)
+        if variant in ("counted", "uncut", "counted packets"):
+            p.flags |= pkg.RT_FLAG_COUNTERS
+        if variant == "uncut":
+            p.flags |= pkg.RT_FLAG_NO_CULL
+        if "packets" in variant:
+            p.flags |= pkg.RT_FLAG_PACKETS
         ctx.reset_counters()
         got = ctx.render(cam, p, None if start is None else start.copy())
         cnt = ctx.counters()
@@ -89,10 +100,13 @@ def render_both_ways(pkg, ctx, cam, params, want, cnt_o, start=None, nan_ok=Fals
                                  f"(x={xs[0]}, y={ys[0]}): got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]}")
         if variant == "uncut":
             assert np.array_equal(cnt, cnt_o), f"{what}: work counters of the uncut render differ: gpu {cnt} oracle {cnt_o}"
-        elif variant == "counted":
-            assert np.array_equal(cnt[[2, 3, 5]], cnt_o[[2, 3, 5]]), f"{what}: rays/hits/paths differ: gpu {cnt} oracle {cnt_o}"
-            assert (cnt[[0, 1, 4]] <= cnt_o[[0, 1, 4]]).all(), f"{what}: more work than the reference: gpu {cnt} oracle {cnt_o}"
-            out = (got, cnt)
-        elif not (params.flags & pkg.RT_FLAG_COUNTERS):
+        elif p.flags & pkg.RT_FLAG_COUNTERS:
+            assert np.array_equal(cnt[[2, 3, 5]], cnt_o[[2, 3, 5]]), f"{what} ({variant}): rays/hits/paths differ: gpu {cnt} oracle {cnt_o}"
+            assert (cnt[[0, 1, 4]] <= cnt_o[[0, 1, 4]]).all(), f"{what} ({variant}): more work than the reference: gpu {cnt} oracle {cnt_o}"
+            if variant == "counted":
+                out = (got, cnt)
+            else:   # the packets give every ray the reference's own visit order: same work as lane by lane
+                assert np.array_equal(cnt, out[1]), f"{what}: packets counted {cnt}, lane by lane {out[1]}"
+        else:
             assert not cnt.any(), f"{what}: a render without RT_FLAG_COUNTERS counted {cnt}"
     return out
