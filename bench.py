@@ -79,23 +79,55 @@ def executed_lane_ops(c, culled: bool) -> float:
     return (27.0 + (22.0 if culled else 0.0)) * box + 60.0 * tri + 150.0 * rays
 
 
-def load_pmc(workload: str, kernel: str, build: str, fix_invdir: bool):
-    """PMC figures per frame of `kernel` from profiles/pmc_traffic.json -- only if they were taken with THIS build of
-    the library on THIS workload (the file carries the build id of the library that was profiled)."""
+def pmc_key(workload: str, fix_invdir: bool) -> str:
+    return workload + ("+fix_invdir" if fix_invdir else "")
+
+
+def load_pmc(key: str, kernels, build: str):
+    """PMC figures per frame, summed over the kernel classes `kernels`, from profiles/pmc_traffic.json -- only if its entry
+    for this workload was taken with THIS build of the library (every entry carries the build id of the library that was
+    profiled).  Returns (dict, None) or (None, reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             tj = json.load(f)
     except (OSError, ValueError):
         return None, "profiles/pmc_traffic.json missing"
-    if tj.get("_build") != build:
-        return None, f"profiles/pmc_traffic.json is of build {tj.get('_build')}, the library is {build}"
-    if tj.get("_workload") != workload or fix_invdir:
-        return None, f"profiles/pmc_traffic.json is of workload {tj.get('_workload')}"
-    k = tj.get(kernel)
-    if not k or k.get("hbm_bytes_per_frame") is None:
-        return None, f"profiles/pmc_traffic.json has no entry for {kernel}"
-    return dict(k, _source=tj.get("_source"), _frames_per_launch=tj.get("_frames_per_launch")), None
+    e = tj.get("workloads", {}).get(key)
+    if e is None:
+        return None, f"profiles/pmc_traffic.json has no entry for {key}"
+    if e.get("_build") != build:
+        return None, f"profiles/pmc_traffic.json[{key}] is of build {e.get('_build')}, the library is {build}"
+    out = {"_source": e.get("_source"), "_frames_per_launch": e.get("_frames_per_launch")}
+    for k in kernels:
+        c = e.get(k)
+        if not c or c.get("hbm_bytes_per_frame") is None:
+            return None, f"profiles/pmc_traffic.json[{key}] has no entry for {k}"
+        for f_ in ("hbm_bytes_per_frame", "l2_bytes_per_frame", "l1_accesses_per_frame", "l2_hits_per_frame", "l2_misses_per_frame",
+                   "ta_busy_cycles_per_frame", "busy_cu_cycles_per_frame"):
+            if c.get(f_) is not None:
+                out[f_] = out.get(f_, 0.0) + float(c[f_])
+    if out.get("l2_hits_per_frame") is not None and out.get("l2_misses_per_frame") is not None:
+        tot = out["l2_hits_per_frame"] + out["l2_misses_per_frame"]
+        out["l2_hit_rate"] = round(out["l2_hits_per_frame"] / tot, 4) if tot > 0 else None
+    if out.get("ta_busy_cycles_per_frame") is not None and out.get("busy_cu_cycles_per_frame"):
+        out["ta_busy_frac"] = round(out["ta_busy_cycles_per_frame"] / out["busy_cu_cycles_per_frame"], 4)
+    return out, None
+
+
+def roofline_dict(valu, hbm, l2, rest):
+    """The roofline object of the JSON line: all views, the binding one (largest fraction) on top."""
+    views = {"valu": valu}
+    if hbm is not None:
+        views["hbm"] = hbm
+    if l2 is not None:
+        views["l2"] = l2
+    bound = max(views, key=lambda k: views[k]["frac"])
+    top = views[bound]
+    out = {"bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"]}
+    out.update(rest)
+    out.update({"valu": valu, "hbm": hbm, "l2": l2})
+    return out
 
 
 def main() -> int:
@@ -306,6 +338,12 @@ def main() -> int:
     ctx.set_profiling(False)
     names = pkg.KERNEL_CLASS_NAMES
     dominant = int(np.argmax(ms))
+    # The default pipeline may trace a launch's primary rays tile by tile in k_primary ahead of the path kernel: the two
+    # kernels then share the traversal work the counters describe and are rated together, durations added.
+    i_paths, i_primary = names.index("paths"), names.index("primary")
+    pair = names[dominant] in ("paths", "primary") and launches[i_primary] > 0
+    if pair:
+        dominant = i_paths
     # algorithmic work of the dominant kernel class alone: for the wavefront extend kernel that is the
     # traversal work of the first RT_WF_BOUNCES(=2) bounces, which a 2-bounce counting pass isolates
     if names[dominant] == "extend":
@@ -316,13 +354,17 @@ def main() -> int:
         dom_counters = counters.copy()
     dom_executed = executed if names[dominant] == "paths" else dom_counters
     n_launch = max(1, int(launches[dominant]))
-    dom_ms = float(ms[dominant]) / n_launch
+    dom_ms = (float(ms[dominant]) + (float(ms[i_primary]) if pair else 0.0)) / n_launch
+    dom_kernels = ["primary", "paths"] if pair else [names[dominant]]
     dom_s = dom_ms * 1e-3 if dom_ms > 0 else float("inf")
     dom_bytes_per_launch = algorithmic_bytes(dom_counters) / n_launch
     dom_ops_per_launch = algorithmic_lane_ops(dom_counters) / n_launch
     frames_per_launch = args.steps / n_launch  # whole-image frames (a launch over a band counts by its share of the rows)
 
-    pmc, pmc_why = load_pmc(args.workload, names[dominant], build_id, args.fix_invdir or args.reuse_primary or args.no_cull)
+    if args.reuse_primary or args.no_cull or args.pipeline != "paths":
+        pmc, pmc_why = None, "no PMC record is kept for this variant"
+    else:
+        pmc, pmc_why = load_pmc(pmc_key(args.workload, args.fix_invdir), dom_kernels, build_id)
     traffic = hbm = l2 = vmem = None
     if pmc is not None:
         traffic = round(pmc["hbm_bytes_per_frame"] * frames_per_launch)
@@ -359,8 +401,9 @@ def main() -> int:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes, "
-                            f"procedural stand-in for the reference's unpublished dragon), {W}x{H}, 1 spp per frame, "
+                "workload": f"{args.workload}: {obj} ({scene.num_tris} triangles, {scene.num_nodes} BVH nodes"
+                            + (", procedural stand-in for the reference's unpublished dragon" if str(obj).startswith("dragon80k") else "")
+                            + f"), {W}x{H}, 1 spp per frame, "
                             f"100 bounces, Russian roulette, {'fix_invdir' if args.fix_invdir else 'bug-compatible invDir'}"
                             + (", RT_FLAG_NO_CULL (the reference's literal traversal)" if args.no_cull else "")
                             + (", one call of the boundary per frame with ping-pong buffers (the reference's loop, main.cpp:183-203)"
@@ -403,38 +446,39 @@ def main() -> int:
             },
             "kernels_ms_per_frame": {names[k]: round(float(ms[k]) / args.steps, 4) for k in range(len(names)) if launches[k]},
             "image_mean_rgb": [round(x, 5) for x in image_mean],
-            # The ceiling that binds this kernel is vector-instruction issue (the scene is cache-resident, HBM and L2
-            # are far from their peaks, there is no matrix work): achieved = the arithmetic of the reference's traversal
-            # of these rays (27 lane-ops per box test, 60 per triangle test, 150 per ray, on the reference's own counts)
-            # per second; `executed` prices what the kernel ran instead.
-            "roofline": {
-                "bound": "valu",
-                "kernel": names[dominant],
-                "achieved": round(tlane, 3),
-                "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2),
-                "unit": "Tlane-op/s",
-                "frac": round(tlane * 1e12 / VALU_PEAK_LANE_OPS, 4),
-                "traffic": traffic,
-                "launch_ms": round(dom_ms, 4),
-                "launches": n_launch,
-                "frames_per_launch": round(frames_per_launch, 3),
-                "lane_ops_per_launch": round(dom_ops_per_launch, 0),
-                "frac_end_to_end": round(algorithmic_lane_ops(counters_all) / elapsed / VALU_PEAK_LANE_OPS / world, 4),
-                "executed": {"achieved": round(executed_lane_ops(dom_executed, culled) / n_launch / dom_s / 1e12, 3),
-                             "frac": round(executed_lane_ops(dom_executed, culled) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
-                             "frac_without_cull_tests": round(algorithmic_lane_ops(dom_executed) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
-                             "note": "achieved / frac above price the REFERENCE's traversal of these rays (its box and triangle "
-                                     "test counts) per second; these are the lane-ops the kernel actually ran"},
-                "hbm": hbm,
-                "l2": l2,
-                "vmem_address": vmem,
-                "algorithmic_bytes": {"per_launch": round(dom_bytes_per_launch, 0), "gb_per_s": round(dom_bytes_per_launch / dom_s / 1e9, 1),
-                                      "note": "bytes the reference's access pattern would move; served by L1/L2/LDS here, not a "
-                                              "fraction of any peak"},
-                "note": ("traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per frame of 16-frame launches of this build ("
-                         + str(pmc.get("_source")) + ") x frames per launch of this run") if pmc is not None
-                        else f"traffic: null -- {pmc_why}",
-            },
+            # Three candidate ceilings, all reported; `bound` names the one with the largest fraction and achieved / peak /
+            # unit / frac are that view's.  valu: the arithmetic of the REFERENCE's traversal of these rays (27 lane-ops per
+            # box test, 60 per triangle test, 150 per ray, on the reference's own counts) per second against the chip's fp32
+            # lane-operation rate; frac_executed prices what the kernels ran instead (fewer box tests: subtrees a bounce ray
+            # cannot reach are skipped).  hbm / l2: PMC traffic of this build against the HBM / aggregate L2 peak.
+            "roofline": roofline_dict(
+                valu={"achieved": round(tlane, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2), "unit": "Tlane-op/s",
+                      "frac": round(tlane * 1e12 / VALU_PEAK_LANE_OPS, 4)},
+                hbm=hbm, l2=l2,
+                rest={
+                    "kernel": "+".join(dom_kernels),
+                    "frac_executed": round(algorithmic_lane_ops(dom_executed) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
+                    "traffic": traffic,
+                    "launch_ms": round(dom_ms, 4),
+                    "launches": n_launch,
+                    "frames_per_launch": round(frames_per_launch, 3),
+                    "lane_ops_per_launch": round(dom_ops_per_launch, 0),
+                    "frac_end_to_end": round(algorithmic_lane_ops(counters_all) / elapsed / VALU_PEAK_LANE_OPS / world, 4),
+                    "executed": {"achieved": round(executed_lane_ops(dom_executed, culled) / n_launch / dom_s / 1e12, 3),
+                                 "frac": round(executed_lane_ops(dom_executed, culled) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
+                                 "frac_without_cull_tests": round(algorithmic_lane_ops(dom_executed) / n_launch / dom_s / VALU_PEAK_LANE_OPS, 4),
+                                 "note": "frac prices the REFERENCE's traversal of these rays (its box and triangle test counts) per "
+                                         "second; these are the lane-ops the kernels actually ran, with and without the arithmetic of "
+                                         "the cull test itself (frac_without_cull_tests = roofline.frac_executed)"},
+                    "vmem_address": vmem,
+                    "algorithmic_bytes": {"per_launch": round(dom_bytes_per_launch, 0), "gb_per_s": round(dom_bytes_per_launch / dom_s / 1e9, 1),
+                                          "note": "bytes the reference's access pattern would move; served by L1/L2/LDS here, not a "
+                                                  "fraction of any peak"},
+                    "note": ("launch_ms = " + " + ".join("k_" + k for k in dom_kernels) + " of one launch, each timed alone with HIP events on "
+                             "the launch stream; " if pair else "")
+                            + (("traffic = PMC (2*FETCH_SIZE + WRITE_SIZE) KiB per frame of this build (" + str(pmc.get("_source"))
+                                + ") x frames per launch of this run") if pmc is not None else f"traffic: null -- {pmc_why}"),
+                }),
         }
         if dist is not None:
             rs = sorted(reduce_ms)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Turns the PMC passes of tools/profile_bench.sh into profiles/pmc_traffic.json, the file bench.py reads for
-roofline.traffic / roofline.hbm / roofline.l2.
+"""Turns the PMC passes of tools/profile_bench.sh into one entry of profiles/pmc_traffic.json, the file bench.py reads for
+roofline.traffic / roofline.hbm / roofline.l2.  The file holds one entry per workload ("workloads": {key: ...}; key = the
+bench.py workload name, "+fix_invdir" appended for that mode); entries of other workloads are kept.
 
-The file is stamped with the build id of the library that was profiled (the "build" field bench.py printed in those
+Every entry is stamped with the build id of the library that was profiled (the "build" field bench.py printed in those
 runs, i.e. the hash of the kernel sources); bench.py quotes the figures only when its own library has the same id.
 
 Units and corrections (MI355X guide, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
@@ -20,7 +21,7 @@ Only launches of <frames per launch> frames are wanted: run profile_bench.sh wit
 multiples of it (bench.py then issues nothing but full launches); the few odd ones are dropped by keeping the upper half
 of the launches of each kernel.
 
-usage: pmc_traffic.py <gpurun_out/prof_TAG> <frames per launch> [out.json] [workload]
+usage: pmc_traffic.py <gpurun_out/prof_TAG> <frames per launch> [out.json] [workload key]
 """
 import collections
 import csv
@@ -29,7 +30,7 @@ import json
 import os
 import sys
 
-CLASS = {"k_paths": "paths", "k_accumulate": "accumulate", "k_mega": "mega", "k_extend": "extend", "k_shade": "shade",
+CLASS = {"k_primary": "primary", "k_paths": "paths", "k_accumulate": "accumulate", "k_mega": "mega", "k_extend": "extend", "k_shade": "shade",
          "k_tail": "tail", "k_generate": "generate"}
 WANTED = ("FETCH_SIZE", "WRITE_SIZE", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum",
           "TA_TA_BUSY_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_BUSY_CU_CYCLES")
@@ -64,9 +65,7 @@ def main():
     builds.discard(None)
     if len(builds) != 1:
         sys.exit(f"the bench outputs under {d} name {sorted(builds)} builds; need exactly one")
-    res = {"_source": os.path.basename(d.rstrip("/")), "_build": builds.pop(), "_frames_per_launch": frames, "_workload": workload,
-           "_formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; l2_bytes = (TCP_TCC_READ_REQ + TCP_TCC_WRITE_REQ) * 64; "
-                       "per launch of _frames_per_launch frames (upper half of the launches), divided by that for per frame"}
+    res = {"_source": os.path.basename(d.rstrip("/")), "_build": builds.pop(), "_frames_per_launch": frames}
     for cls, c in vals.items():
         e = {}
         if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
@@ -78,13 +77,26 @@ def main():
             e.update(l2_read_req=round(rd), l2_write_req=round(wr), l2_bytes_per_frame=round((rd + wr) * 64 / frames))
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
             h, m = upper_half_mean(c["TCC_HIT_sum"]), upper_half_mean(c["TCC_MISS_sum"])
-            e.update(l2_hit_rate=round(h / (h + m), 4) if h + m > 0 else None)
+            e.update(l2_hit_rate=round(h / (h + m), 4) if h + m > 0 else None, l2_hits_per_frame=round(h / frames),
+                     l2_misses_per_frame=round(m / frames))
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
             # vector-memory address unit: one lane address (one cache-line access) per cycle and CU
             e.update(l1_accesses_per_frame=round(upper_half_mean(c["TCP_TOTAL_CACHE_ACCESSES_sum"]) / frames))
         if "TA_TA_BUSY_sum" in c and "SQ_BUSY_CU_CYCLES" in c:
-            e.update(ta_busy_frac=round(upper_half_mean(c["TA_TA_BUSY_sum"]) / upper_half_mean(c["SQ_BUSY_CU_CYCLES"]), 4))
+            ta, busy = upper_half_mean(c["TA_TA_BUSY_sum"]), upper_half_mean(c["SQ_BUSY_CU_CYCLES"])
+            e.update(ta_busy_frac=round(ta / busy, 4), ta_busy_cycles_per_frame=round(ta / frames), busy_cu_cycles_per_frame=round(busy / frames))
         res[cls] = e
+    try:
+        with open(out) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        doc = {}
+    if "workloads" not in doc:
+        doc = {"workloads": {}}
+    doc["_formula"] = ("hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; l2_bytes = (TCP_TCC_READ_REQ + TCP_TCC_WRITE_REQ) * 64; per launch of "
+                       "_frames_per_launch frames (upper half of the launches), divided by that for per frame")
+    doc["workloads"][workload] = res
+    res = doc
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--counters", action="store_true", help="render with RT_FLAG_COUNTERS and print the work counters")
     ap.add_argument("--per-frame", action="store_true", help="one rt_raytrace_frame call per frame (ping-pong buffers), as the reference's loop does")
     ap.add_argument("--bands", type=int, default=0, help="time every band of an N-way tile partition on this one GPU")
+    ap.add_argument("--standalone", type=int, default=0,
+                    help="after the warm-up, this many calls of --frames frames each (at most one launch's worth), every one "
+                         "synchronised before the next: launches that have the chip to themselves, for a kernel trace")
     a = ap.parse_args()
     pkg = entry.load_package()
     obj, pos = SCENES[a.scene]
@@ -69,6 +72,22 @@ def main():
                 ms.append(best)
             print(f"{a.bands} {'interleaved' if inter else 'contiguous'} bands, ms per frame per band: "
                   + " ".join(f"{x:.3f}" for x in ms) + f" | max {max(ms):.3f} mean {sum(ms) / len(ms):.3f} balance {sum(ms) / len(ms) / max(ms):.2f}")
+        ctx.close()
+        return
+    if a.standalone:
+        buf = pkg.DeviceBuffer(a.width * a.height * 16)
+        p = pkg.make_params(a.width, a.height, frames=a.frames, flags=flags)
+        ctx.render_device(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags), buf.ptr)
+        ctx.synchronize()
+        ms = []
+        for _ in range(a.standalone):
+            t0 = time.perf_counter()
+            ctx.render_device(cam, p, buf.ptr)
+            ctx.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        print(f"{a.pipeline} {a.scene} {a.width}x{a.height}: {a.standalone} synchronised calls of {a.frames} frames: "
+              f"mean {sum(ms) / len(ms):.3f} min {min(ms):.3f} max {max(ms):.3f} ms per call (host clock)")
+        buf.free()
         ctx.close()
         return
     if a.per_frame:

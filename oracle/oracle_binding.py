@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
+_variant = None
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -19,10 +20,12 @@ c_uint32_p = C.POINTER(C.c_uint32)
 c_u64_p = C.POINTER(C.c_uint64)
 
 
-def load() -> C.CDLL:
-    global _lib
-    if _lib is None:
-        path = os.path.join(_HERE, "librt_oracle.so")
+def load(variant: bool = False) -> C.CDLL:
+    """librt_oracle.so, or with variant=True librt_oracle_variant.so: the same code over another admissible reading of the
+    GLSL built-ins (rt_math_variant.h), for measuring how far the unpinned part of the numerics contract can move an image."""
+    global _lib, _variant
+    if (_variant if variant else _lib) is None:
+        path = os.path.join(_HERE, "librt_oracle_variant.so" if variant else "librt_oracle.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: make -C {_HERE}")
         lib = C.CDLL(path)
@@ -52,8 +55,11 @@ def load() -> C.CDLL:
         lib.oracle_math.restype = None
         lib.oracle_max_threads.argtypes = []
         lib.oracle_max_threads.restype = C.c_int
-        _lib = lib
-    return _lib
+        if variant:
+            _variant = lib
+        else:
+            _lib = lib
+    return _variant if variant else _lib
 
 
 def _f(a):
@@ -72,13 +78,13 @@ def normals(scene) -> np.ndarray:
     return out
 
 
-def render(scene, cam, params, accum=None, threads=0):
+def render(scene, cam, params, accum=None, threads=0, variant=False):
     """Returns (rgba[H,W,4], counters[6])."""
     s = scene.as_rt_scene()
     if accum is None:
         accum = np.zeros((params.height, params.width, 4), dtype=np.float32)
     counters = (C.c_uint64 * 6)()
-    load().oracle_render(C.byref(s), C.byref(cam), C.byref(params), _f(accum), counters, threads)
+    load(variant).oracle_render(C.byref(s), C.byref(cam), C.byref(params), _f(accum), counters, threads)
     return accum, np.array(list(counters), dtype=np.uint64)
 
 
@@ -90,11 +96,11 @@ def frame_rows(scene, nrm, cam, params, frame_count, out, row_begin, row_end, th
     return np.array(list(counters), dtype=np.uint64)
 
 
-def primary_hits(scene, cam, width, height, brute_force=False, threads=0):
+def primary_hits(scene, cam, width, height, brute_force=False, threads=0, variant=False):
     s = scene.as_rt_scene()
     ids = np.empty((height, width), dtype=np.int32)
     t = np.empty((height, width), dtype=np.float32)
-    load().oracle_primary_hits(C.byref(s), C.byref(cam), width, height, int(brute_force),
+    load(variant).oracle_primary_hits(C.byref(s), C.byref(cam), width, height, int(brute_force),
                                ids.ctypes.data_as(c_int32_p), _f(t), threads)
     return ids, t
 
