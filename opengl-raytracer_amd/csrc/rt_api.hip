@@ -146,6 +146,9 @@ struct rt_context {
     hipEvent_t phits_ready = nullptr;  // recorded on the context's stream after the pass that fills d_phits
     // primary rays traced per tile by k_primary (rt_packets.h): the hits it queues for the path kernel, one share per
     // pipeline slot like the staged samples
+    float4* d_rnodes = nullptr;   // rebased inner-node records (k_rebase), one copy of rnodes_cap records per pipeline slot;
+    size_t rnodes_cap = 0;        // allocated by the first launch that traces packets, kept while the scene's records fit
+    size_t num_recs = 0;          // inner-node records of the current scene
     float4* d_hitq = nullptr;
     uint32_t* d_hcount = nullptr;
     size_t hitq_items = 0;        // (tile, frame) items the two buffers hold, all slots together
@@ -301,6 +304,8 @@ static void free_ref(rt_context* c) {
 }
 
 static void free_scene(rt_context* c) {
+    dfree(c->d_rnodes);
+    c->rnodes_cap = 0;
     dfree(c->d_nodes);
     dfree(c->d_tris);
     dfree(c->d_shade);
@@ -431,6 +436,11 @@ static uint32_t paths_batch(size_t pixels) {
     return (uint32_t)(fit < 1 ? 1 : (fit > PT_MAX_BATCH ? PT_MAX_BATCH : fit));
 }
 
+// rays_per_pixel > 1 runs on the default pipeline as long as one frame's samples fit a launch's staging share.
+static bool rpp_fits_paths(const rt_params* p) {
+    return p->rays_per_pixel <= paths_batch((size_t)p->width * p->height);
+}
+
 // Frames traced ahead and then not asked for (the camera moved, the frame count jumped) are only forgotten: their
 // launches run to the end on their internal streams, and whatever follows on such a stream -- the next launch into the
 // same staging slot -- is ordered behind them by the stream itself.  The context's stream does not wait for them, so the
@@ -547,6 +557,7 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.frame_stride = stride;
     a.num_frames = nframes;
     a.bounces = p->ray_bounces;
+    a.rpp = p->rays_per_pixel;
     a.tiles_x = (p->width + 7) / 8;
     a.tile_y0 = bl.tile_y0;
     a.stripe_period = bl.stripe_period;
@@ -564,6 +575,7 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     a.chunk = nframes == 1 ? (uint32_t)c->tune_frame_chunk : 1u;
     if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
     a.hits = nullptr;
+    a.rnodes = nullptr;
     a.hitq = nullptr;
     a.hcount = nullptr;
     a.samples = nullptr;
@@ -607,6 +619,9 @@ static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsAr
     } else if (pmode == PM_REUSE) {
         if (count) { if (fix) PATHS(true, true, PM_REUSE); else PATHS(true, false, PM_REUSE); }
         else { if (fix) PATHS(false, true, PM_REUSE); else PATHS(false, false, PM_REUSE); }
+    } else if (pmode == PM_MULTI) {
+        if (count) { if (fix) PATHS(true, true, PM_MULTI); else PATHS(true, false, PM_MULTI); }
+        else { if (fix) PATHS(false, true, PM_MULTI); else PATHS(false, false, PM_MULTI); }
     } else if (pmode == PM_QUEUE) {
         if (count) { if (fix) PATHS(true, true, PM_QUEUE); else PATHS(true, false, PM_QUEUE); }
         else { if (fix) PATHS(false, true, PM_QUEUE); else PATHS(false, false, PM_QUEUE); }
@@ -627,7 +642,7 @@ static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsAr
 // pixels) 1.03 -> 0.93, 9.27 M-triangle grid (1 pixel: a tile's rays part ways a few levels down) 0.99 -> 1.12.  With
 // RT_FLAG_FIX_INVDIR most of the work is bounce rays and splitting the primary rays off loses (0.51 -> 0.58).
 static bool use_packets(const rt_context* c, const rt_params* p, const DCamera& dc) {
-    if (c->tune_packets == 0 || (p->flags & (RT_FLAG_NO_CULL | RT_FLAG_REUSE_PRIMARY))) return false;
+    if (c->tune_packets == 0 || (p->flags & (RT_FLAG_NO_CULL | RT_FLAG_REUSE_PRIMARY)) || p->rays_per_pixel != 1) return false;
     if (c->tune_packets >= 2 || (p->flags & RT_FLAG_PACKETS)) return true;
     if (p->flags & RT_FLAG_FIX_INVDIR) return false;
     const double ex = (double)c->sc.rmax[0] - c->sc.rmin[0], ey = (double)c->sc.rmax[1] - c->sc.rmin[1], ez = (double)c->sc.rmax[2] - c->sc.rmin[2];
@@ -642,9 +657,32 @@ static bool use_packets(const rt_context* c, const rt_params* p, const DCamera& 
     return tri >= 3.0 * pixel;   // NaN (degenerate box or camera): false
 }
 
+// Room for the rebased copies of the scene's inner-node records, one per pipeline slot.
+static int ensure_rnodes(rt_context* c) {
+    if (c->num_recs <= c->rnodes_cap && c->d_rnodes) return RT_OK;
+    ahead_reset(c);   // launches in flight may still read the old copies
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamSynchronize(c->lane_stream[k]));
+    dfree(c->d_rnodes);
+    c->rnodes_cap = 0;
+    const size_t cap = c->num_recs + c->num_recs / 16 + 1;   // a rebuilt tree's record count wanders a little
+    HIPCHK(c, hipMalloc(&c->d_rnodes, cap * RT_LANES * 4 * sizeof(float4)));
+    c->rnodes_cap = cap;
+    return RT_OK;
+}
+
 // Points the launch at pipeline slot `slot`'s share of the hit queues and traces the primary rays of its items on `st`;
 // the path kernel that follows on the same stream runs in PM_QUEUE mode.
 static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, bool count, hipStream_t st) {
+    // the slot's copy of the inner-node records, box corners minus this launch's ray origin (the counting build reads the
+    // records as they are)
+    float4* const rn = c->d_rnodes + (size_t)slot * c->rnodes_cap * 4;
+    a.rnodes = rn;
+    if (!count && c->num_recs) {
+        const uint32_t quads = (uint32_t)(c->num_recs * 4);
+        hipLaunchKernelGGL(k_rebase, dim3((quads + 255u) / 256u), dim3(256), 0, st, (const float4*)c->d_nodes, rn, quads, dc.pos[0], dc.pos[1],
+                           dc.pos[2]);
+    }
     const size_t share = c->hitq_items / RT_LANES;
     a.hitq = c->d_hitq + (size_t)slot * share * 64;
     a.hcount = c->d_hcount + (size_t)slot * share;
@@ -662,7 +700,7 @@ static void launch_k_accumulate(const rt_context* c, const rt_params* p, const B
     if (bl.px.num_pixels)
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((bl.px.num_pixels + 255) / 256)), dim3(256), 0, c->stream,
                            (const float4*)a.samples, a.num_frames, a.pixels, bl.px, a.frame_base, a.frame_stride, sum ? 1u : 0u,
-                           read_prev, prev, out);
+                           read_prev, prev, out, a.rpp);
 }
 
 // RT_FLAG_REUSE_PRIMARY: makes sure c->d_phits holds the closest hits of the primary rays of (camera, size, band, current
@@ -753,6 +791,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     }
     if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
     const bool packets = use_packets(c, p, dc);
+    if (packets && (rc = ensure_rnodes(c)) != RT_OK) return rc;
     if (packets && pipelined) {
         if ((rc = launch_k_primary_pipelined(c, dc, a, slot, pst)) != RT_OK) return rc;
     } else if (packets) {
@@ -761,7 +800,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     }
     {
         LaunchTimer lt(c, RT_K_PATHS);
-        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : (packets ? PM_QUEUE : PM_TRACE), pipelined, pst);
+        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : packets ? PM_QUEUE : a.rpp > 1u ? PM_MULTI : PM_TRACE, pipelined, pst);
     }
     HIPCHK(c, hipGetLastError());
     if (pipelined) {
@@ -792,7 +831,7 @@ static int launch_ahead(rt_context* c, const DCamera& dc, const rt_params* p, ui
     a.spill = c->d_pspill ? c->d_pspill + (size_t)slot * c->pspill_entries * a.spill_stride : nullptr;
     hipStream_t pst = c->lane_stream[slot];
     HIPCHK(c, hipStreamWaitEvent(pst, c->slot_free[slot], 0));  // the slot's last reader has finished
-    const bool packets = use_packets(c, p, dc);
+    const bool packets = use_packets(c, p, dc);   // frame_call has made room for the rebased records
     int rc;
     if (packets && (rc = launch_k_primary_pipelined(c, dc, a, slot, pst)) != RT_OK) return rc;
     launch_k_paths(c, dc, a, false, (p->flags & RT_FLAG_FIX_INVDIR) != 0, packets ? PM_QUEUE : PM_TRACE, true, pst);
@@ -807,7 +846,12 @@ static int launch_ahead(rt_context* c, const DCamera& dc, const rt_params* p, ui
 // single-frame launch.
 static int frame_call(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_count, const float4* prev, float4* out) {
     rt_context::Ahead& ah = c->ahead;
-    const bool eligible = c->tune_ahead >= 2 && !c->profiling && !(p->flags & (RT_FLAG_COUNTERS | RT_FLAG_REUSE_PRIMARY));
+    if (use_packets(c, p, dc)) {   // before any launch is recorded as traced ahead: a reallocation drops what is in flight
+        const int rc0 = ensure_rnodes(c);
+        if (rc0 != RT_OK) return rc0;
+    }
+    const bool eligible = c->tune_ahead >= 2 && !c->profiling && !(p->flags & (RT_FLAG_COUNTERS | RT_FLAG_REUSE_PRIMARY)) &&
+                          p->rays_per_pixel == 1;
     if (!eligible) {
         ahead_reset(c);
         return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, prev, out, true);
@@ -1223,6 +1267,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
         }
     }
 
+    c->num_recs = nrec;
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
     c->sc.shade = c->d_shade;
@@ -1412,6 +1457,7 @@ static int build_core(rt_context* c) {
 
     bd.cur = cur;
     bd.parents_valid = false;
+    c->num_recs = (size_t)num_recs;
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
     c->sc.shade = c->d_shade;
@@ -1593,9 +1639,10 @@ int rt_raytrace_frame(rt_context* c, const rt_camera* cam, const rt_params* p, u
     const bool sum = (p->flags & RT_FLAG_SUM) != 0;
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
-    const bool mega = (p->flags & RT_FLAG_MEGAKERNEL) != 0 || p->render_mode != RT_MODE_RENDER ||
-                      p->rays_per_pixel != 1 || p->ray_bounces == 0;
-    const bool wavefront = !mega && (p->flags & RT_FLAG_WAVEFRONT) != 0;
+    const bool wf_asked = (p->flags & RT_FLAG_WAVEFRONT) != 0;
+    const bool mega = (p->flags & RT_FLAG_MEGAKERNEL) != 0 || p->render_mode != RT_MODE_RENDER || p->ray_bounces == 0 ||
+                      (p->rays_per_pixel != 1 && (wf_asked || !rpp_fits_paths(p)));
+    const bool wavefront = !mega && wf_asked;
     if (!d_prev_frame && (sum || frame_count != 0)) return fail(c, RT_EINVAL, "d_prev_frame is NULL for frame %u", frame_count);
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
@@ -1716,7 +1763,7 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
             HIPCHK(c, hipMemsetAsync(d_accum + (size_t)r.first * p->width * 4, 0, (size_t)r.second * p->width * 4 * sizeof(float), c->stream));
     }
     const bool per_frame = (p->flags & (RT_FLAG_MEGAKERNEL | RT_FLAG_WAVEFRONT)) != 0 ||
-                           p->render_mode != RT_MODE_RENDER || p->rays_per_pixel != 1 || p->ray_bounces == 0;
+                           p->render_mode != RT_MODE_RENDER || !rpp_fits_paths(p) || p->ray_bounces == 0;
     if (per_frame) {
         for (uint32_t f = 0; f < p->frames; f++) {
             uint32_t fc = p->frame_base + f * stride;
@@ -1727,7 +1774,7 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     }
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
-    const uint32_t batch = paths_batch((size_t)p->width * p->height);
+    const uint32_t batch = paths_batch((size_t)p->width * p->height) / p->rays_per_pixel;  // frames x samples staged per launch
     for (uint32_t f = 0; f < p->frames; f += batch) {
         uint32_t n = p->frames - f < batch ? p->frames - f : batch;
         rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, true);

@@ -34,6 +34,23 @@ typedef float pk_f4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) pk_f4* pk_cf4;   // constant address space: uniform addresses load through the scalar cache
 
 
+// The primary rays of a launch leave one point, so the first half of every slab test -- box corner minus ray origin
+// (raytrace.glsl:115-116) -- is the same for all of them: k_rebase does those subtractions once per launch, into a copy of the
+// inner-node records that k_primary<false> reads (12 of the ~66 vector instructions of a packet's node visit).  The same
+// binary32 subtraction, done earlier: results are bit-identical.
+__global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out, uint32_t num_quads, float ox, float oy, float oz) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= num_quads) return;
+    float4 q = nodes[i];
+    switch (i & 3u) {
+        case 0: q = make_float4(q.x - ox, q.y - oy, q.z - oz, q.w - ox); break;   // c1.min.xyz c1.max.x
+        case 1: q = make_float4(q.x - oy, q.y - oz, q.z - ox, q.w - oy); break;   // c1.max.yz  c2.min.xy
+        case 2: q = make_float4(q.x - oz, q.y - ox, q.z - oy, q.w - oz); break;   // c2.min.z   c2.max.xyz
+        default: break;                                                          // child references
+    }
+    out[i] = q;
+}
+
 // The packet's whole traversal, hand-written: the step is bound by the scalar unit (one scalar instruction per four cycles
 // and SIMD), and the compiler's version of the ordering and stack logic took ~125 scalar and branch instructions per node
 // where ~30 do.  Same algorithm, statement for statement, as the loop in k_primary<true> below (which the counting build
@@ -41,7 +58,8 @@ typedef const __attribute__((address_space(4))) pk_f4* pk_cf4;   // constant add
 // masks live in SGPRs, the packet's stack in three VGPRs (lane i = entry i, v_writelane / v_readlane) plus one LDS row of
 // per-lane distances per entry.  The slab test, the triangle test (with the correctly rounded division) and their
 // instruction order are the compiler's own output for box_dist / tri_dist_flat, so results are bit-identical.
-// Registers s36-s91 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
+// `nodes` are the launch's rebased records (k_rebase: box corners minus the common ray origin); the triangle test still
+// needs the origin.  Registers s36-s91 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
 __device__ __forceinline__ bool pk_traverse(unsigned long long nodes, unsigned long long tris, int root, unsigned long long in0,
                                             rt_vec3 o, rt_vec3 d, rt_vec3 inv, uint32_t lrow, float& best, int& best_id) {
     int gave;
@@ -61,18 +79,12 @@ __device__ __forceinline__ bool pk_traverse(unsigned long long nodes, unsigned l
         "s_lshl_b32 s72, s70, 6\n\t"
         "s_load_dwordx16 s[36:51], %[nodes], s72\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32_e32 v40, s36, %[ox]\n\t"
-        "v_sub_f32_e32 v41, s37, %[oy]\n\t"
-        "v_sub_f32_e32 v42, s38, %[oz]\n\t"
-        "v_sub_f32_e32 v43, s39, %[ox]\n\t"
-        "v_sub_f32_e32 v44, s40, %[oy]\n\t"
-        "v_sub_f32_e32 v45, s41, %[oz]\n\t"
-        "v_mul_f32_e32 v40, %[ix], v40\n\t"
-        "v_mul_f32_e32 v41, %[iy], v41\n\t"
-        "v_mul_f32_e32 v42, %[iz], v42\n\t"
-        "v_mul_f32_e32 v43, %[ix], v43\n\t"
-        "v_mul_f32_e32 v44, %[iy], v44\n\t"
-        "v_mul_f32_e32 v45, %[iz], v45\n\t"
+        "v_mul_f32_e32 v40, s36, %[ix]\n\t"      // the record holds (corner - origin) already: k_rebase
+        "v_mul_f32_e32 v41, s37, %[iy]\n\t"
+        "v_mul_f32_e32 v42, s38, %[iz]\n\t"
+        "v_mul_f32_e32 v43, s39, %[ix]\n\t"
+        "v_mul_f32_e32 v44, s40, %[iy]\n\t"
+        "v_mul_f32_e32 v45, s41, %[iz]\n\t"
         "v_min_f32_e32 v46, v40, v43\n\t"
         "v_min_f32_e32 v47, v41, v44\n\t"
         "v_min_f32_e32 v48, v42, v45\n\t"
@@ -81,19 +93,13 @@ __device__ __forceinline__ bool pk_traverse(unsigned long long nodes, unsigned l
         "v_max_f32_e32 v42, v42, v45\n\t"
         "v_max3_f32 v49, v46, v47, v48\n\t"        // tNear
         "v_min3_f32 v50, v40, v41, v42\n\t"        // tFar
-        "v_sub_f32_e32 v40, s42, %[ox]\n\t"
-        "v_sub_f32_e32 v41, s43, %[oy]\n\t"
-        "v_sub_f32_e32 v42, s44, %[oz]\n\t"
-        "v_sub_f32_e32 v43, s45, %[ox]\n\t"
-        "v_sub_f32_e32 v44, s46, %[oy]\n\t"
-        "v_sub_f32_e32 v45, s47, %[oz]\n\t"
         "v_cmp_lt_f32_e64 s[80:81], s90, v49\n\t"  // EPS < tNear
-        "v_mul_f32_e32 v40, %[ix], v40\n\t"
-        "v_mul_f32_e32 v41, %[iy], v41\n\t"
-        "v_mul_f32_e32 v42, %[iz], v42\n\t"
-        "v_mul_f32_e32 v43, %[ix], v43\n\t"
-        "v_mul_f32_e32 v44, %[iy], v44\n\t"
-        "v_mul_f32_e32 v45, %[iz], v45\n\t"
+        "v_mul_f32_e32 v40, s42, %[ix]\n\t"
+        "v_mul_f32_e32 v41, s43, %[iy]\n\t"
+        "v_mul_f32_e32 v42, s44, %[iz]\n\t"
+        "v_mul_f32_e32 v43, s45, %[ix]\n\t"
+        "v_mul_f32_e32 v44, s46, %[iy]\n\t"
+        "v_mul_f32_e32 v45, s47, %[iz]\n\t"
         "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"       // tFar >= tNear
         "v_cmp_lt_f32_e64 s[78:79], s90, v50\n\t"  // EPS < tFar
         "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene s
 
         if (!COUNT) {   // the hand-written loop; the counting build keeps the C++ one below
             const uint32_t lrow = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)&dist_rows[0][lane];
-            gave_up = pk_traverse((unsigned long long)(uintptr_t)sc.nodes, (unsigned long long)(uintptr_t)sc.tris, sc.root_ref,
+            gave_up = pk_traverse((unsigned long long)(uintptr_t)a.rnodes, (unsigned long long)(uintptr_t)sc.tris, sc.root_ref,
                                   __builtin_amdgcn_ballot_w64(in), o, d, inv, lrow, best, best_id);
             cur = RT_REF_IDLE;
         }

@@ -72,11 +72,14 @@ enum { ST_NEED = 0, ST_NEW = 1, ST_TRAV = 2, ST_DONE = 3 };
 //   PM_REUSE    every path starts from the stored hit of its pixel and traces only its bounce rays (RT_FLAG_REUSE_PRIMARY)
 //   PM_QUEUE    the primary rays of the launch have been traced tile by tile by k_primary (rt_packets.h): every path
 //               starts from the hit that kernel queued for it; paths whose primary ray left the scene are already finished
-enum { PM_TRACE = 0, PM_PRIMARY = 1, PM_REUSE = 2, PM_QUEUE = 3 };
+//   PM_MULTI    PM_TRACE for rays_per_pixel > 1: the samples of a pixel share the primary ray and continue ONE random-number
+//               stream (raytrace.glsl:289-293), so they are traced one after the other by the lane that took the pixel
+enum { PM_TRACE = 0, PM_PRIMARY = 1, PM_REUSE = 2, PM_QUEUE = 3, PM_MULTI = 4 };
 
 struct PathsArgs {
     uint32_t frame_base, frame_stride, num_frames;
     uint32_t bounces;
+    uint32_t rpp;                   // u_RaysPerPixel; > 1 only in PM_MULTI: samples are staged [frame][sample][pixel]
     int tiles_x, tiles_per_frame;   // 8x8 pixel tiles (of the band being rendered); tiles_per_frame counts whole strips
     int strip_tiles;                // tiles in one vertical strip: PT_STRIP_W * tile rows of the band
     int tile_y0;                    // first tile row of the band (contiguous band) or of its first stripe (interleaved)
@@ -91,6 +94,7 @@ struct PathsArgs {
                                     // (cull_slack + cull_slope * reach of the box from the ray origin) / 2
     float2* hits;                   // [pixels] closest hit of every pixel's primary ray, (t, id bits): written in PM_PRIMARY, read in PM_REUSE
     float4* hitq;                   // [total_tiles][64] PM_QUEUE: (t, id bits, lane bits, 0) of the k-th primary ray of the item that hit something
+    const float4* rnodes;           // k_primary: the inner-node records with the launch's ray origin subtracted from every box corner (k_rebase)
     uint32_t* hcount;               // [total_tiles] PM_QUEUE: how many did; 0xffffffff: the item's primary rays are still to be traced, lane by lane
     float4* samples;                // [num_frames][pixels]
     uint2* spill;                   // [entries][gridDim.x * PT_BLOCK] or nullptr
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
     p.o = p.d = p.inv = p.thr = rt_v3(0.0f, 0.0f, 0.0f);
     p.seed = 0;
     uint32_t out_idx = 0, bnc = 0;
+    uint32_t smp_left = 0;   // PM_MULTI: samples of the lane's pixel still to trace after the current one
     int cur = RT_REF_IDLE, sp = 0, best_id = -1;
     float best = RT_INF;
     Counters cn = {0, 0, 0, 0, 0};
@@ -354,6 +359,19 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                 if (ended) {
                     a.samples[out_idx] = sample;
                     state = ST_NEED;
+                    if (PMODE == PM_MULTI && smp_left != 0u) {
+                        // the pixel's next sample: the same primary ray again (getColour takes the ray by value), the
+                        // random-number stream goes on where the last path left it
+                        smp_left--;
+                        out_idx += a.pixels;
+                        const uint32_t pix = out_idx % a.pixels;
+                        const int gy = (int)(pix / (uint32_t)cam.width), gx = (int)(pix - (uint32_t)gy * (uint32_t)cam.width);
+                        primary_ray(cam, gx, gy, p.o, p.d, p.inv);
+                        p.thr = rt_v3(1.0f, 1.0f, 1.0f);
+                        bnc = 0;
+                        state = ST_NEW;
+                        if (COUNT) paths++;
+                    }
                 }
             }
             const unsigned long long need = __builtin_amdgcn_ballot_w64(state == ST_NEED);
@@ -395,7 +413,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BLOCK * PT_BLOCKS_PER_CU / 256) void k
                             p.seed = pixel_seed(cam, gx, gy, a.frame_base + f * a.frame_stride);
                             p.thr = rt_v3(1.0f, 1.0f, 1.0f);
                             const uint32_t pix = (uint32_t)gy * (uint32_t)cam.width + (uint32_t)gx;
-                            out_idx = f * a.pixels + pix;
+                            out_idx = (PMODE == PM_MULTI ? f * a.rpp : f) * a.pixels + pix;
+                            if (PMODE == PM_MULTI) smp_left = a.rpp - 1u;
                             bnc = 0;
                             if (PMODE == PM_REUSE) {
                                 // the primary ray's closest hit is known: the path goes straight to its first bounce (or the sky)
@@ -622,9 +641,11 @@ struct BandPixels {
     uint32_t width, row0, stripe_rows, period_rows, num_pixels;
 };
 
+// rpp > 1: frame j's colour is the sum of its rpp staged samples in order, starting from BLACK = (0, 0, 0, 1), divided by rpp
+// (raytrace.glsl:289-293).
 __global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint32_t num_frames, uint32_t pixels, BandPixels bp,
                                                     uint32_t frame_base, uint32_t frame_stride, uint32_t sum_mode,
-                                                    uint32_t read_prev, const float4* prev, float4* out) {
+                                                    uint32_t read_prev, const float4* prev, float4* out, uint32_t rpp) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= bp.num_pixels) return;
     if (bp.period_rows) {
@@ -636,9 +657,22 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4* samples, uint3
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (read_prev) acc = prev[i];
     for (uint32_t j = 0; j < num_frames; j++) {
-        float4 smp = samples[(size_t)j * pixels + i];
-        rt_vec3 sky = rt_mul(sample_sky(rt_v3(0.0f, smp.w, 0.0f)), rt_v3(smp.x, smp.y, smp.z));
-        float4 c = make_float4(sky.x, sky.y, sky.z, 2.0f);
+        float4 c;
+        if (rpp == 1u) {
+            float4 smp = samples[(size_t)j * pixels + i];
+            rt_vec3 sky = rt_mul(sample_sky(rt_v3(0.0f, smp.w, 0.0f)), rt_v3(smp.x, smp.y, smp.z));
+            c = make_float4(sky.x, sky.y, sky.z, 2.0f);
+        } else {
+            c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            for (uint32_t k = 0; k < rpp; k++) {
+                float4 smp = samples[((size_t)j * rpp + k) * pixels + i];
+                rt_vec3 sky = rt_mul(sample_sky(rt_v3(0.0f, smp.w, 0.0f)), rt_v3(smp.x, smp.y, smp.z));
+                // getColour returns result = 0 + sky * throughput, or 0 for a path that never reached the sky
+                c = make_float4(c.x + (0.0f + sky.x), c.y + (0.0f + sky.y), c.z + (0.0f + sky.z), c.w + 1.0f);
+            }
+            const float r = (float)rpp;
+            c = make_float4(c.x / r, c.y / r, c.z / r, c.w / r);
+        }
         uint32_t frame = frame_base + j * frame_stride;
         float fc = (float)frame, fc1 = (float)(frame + 1u);
         bool s = sum_mode != 0;

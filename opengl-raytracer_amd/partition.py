@@ -53,7 +53,7 @@ def band_row_ranges(index: int, count: int, height: int, interleaved: bool = Fal
 
 
 def render_partitioned(*, rank: int, world: int, steps: int, height: int, render, start_reduce, finish,
-                       mode: str = "samples", reduce_bands: int = 1, first_step: int = 0):
+                       mode: str = "samples", reduce_bands: int = 1, first_step: int = 0, launch_frames: int = 16):
     """This rank's share of a partitioned accumulation and the collective that closes it; the renderer and the
     collective are passed in, so the same code runs on RCCL with the HIP library and on gloo with a CPU renderer.
 
@@ -65,11 +65,13 @@ def render_partitioned(*, rank: int, world: int, steps: int, height: int, render
       finish(handle)                                         wait for it
 
     mode 'samples' (weak scaling): rank g renders frameCount (first_step+s)*world + g for s in [0, steps).  The closing
-    reduce costs time in proportion to the rows reduced, whatever the number of frames summed in them, so the image is
-    cut into `reduce_bands` contiguous row bands that are finished one after the other: the reduce of band b travels
-    while band b+1 renders, and only the last band's reduce (1/reduce_bands of the bytes) is exposed.  Bands are
-    bit-identical to the whole image (seeds use global pixel indices).  Rank 0 must scale the reduced sums by
-    1 / (steps * world) afterwards.
+    reduce costs time in proportion to the rows reduced, whatever the number of frames summed in them.  With
+    reduce_bands > 1 only the frames of the rank's LAST launch (the library renders launch_frames frames per launch) are
+    rendered band by band: everything before them goes out as whole-image launches, then the image is finished in
+    `reduce_bands` contiguous row bands one after the other, the reduce of band b travelling while band b+1 renders, so
+    that only the last band's reduce (1/reduce_bands of the bytes) is exposed -- at the price of reduce_bands short
+    launches in place of one.  Bands are bit-identical to the whole image (seeds use global pixel indices, sums add
+    the same numbers in the same order).  Rank 0 must scale the reduced sums by 1 / (steps * world) afterwards.
 
     mode 'tiles' (strong scaling): every rank renders the same `steps` frames, restricted to its INTERLEAVED band
     (band_row_ranges(rank, world, height, True)), running mean; the buffers are zero elsewhere, so one sum-reduce of
@@ -84,12 +86,18 @@ def render_partitioned(*, rank: int, world: int, steps: int, height: int, render
         raise ValueError("mode must be 'samples' or 'tiles'")
     base, stride, frames = rank_frames(rank, world, first_step, steps)
     count = max(1, min(int(reduce_bands), (height + 7) // 8))
+    # the frames before the rank's last launch: whole image, no reduce yet
+    head = 0
+    if count > 1 and frames > 0 and launch_frames > 0:
+        head = frames - ((frames - 1) % launch_frames + 1)
+        if head > 0:
+            render(base, stride, head, None, (0, height))
     pending, done = [], []
     for b in range(count):
         rows = band_rows(b, count, height)
         if rows[1] <= rows[0]:
             continue
-        render(base, stride, frames, None if count == 1 else (b, count), rows)
+        render(base + head * stride, stride, frames - head, None if count == 1 else (b, count), rows)
         pending.append(start_reduce(rows))
         done.append(rows)
     for h in pending:

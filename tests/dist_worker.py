@@ -19,6 +19,7 @@ def main():
     out_path = sys.argv[2]
     mode = sys.argv[3] if len(sys.argv) > 3 else "samples"
     reduce_bands = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    launch_frames = int(sys.argv[5]) if len(sys.argv) > 5 else 16
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = entry.load_package()
     oracle = entry.load_oracle()
@@ -53,7 +54,8 @@ def main():
         return dist.reduce(shared[rows[0]:rows[1]], dst=0, async_op=True)
 
     reduced = partition.render_partitioned(rank=rank, world=world, steps=steps, height=H, render=render, start_reduce=start_reduce,
-                                           finish=lambda work: work.wait(), mode=mode, reduce_bands=reduce_bands)
+                                           finish=lambda work: work.wait(), mode=mode, reduce_bands=reduce_bands,
+                                           launch_frames=launch_frames)
     rays = torch.tensor([rays_local[0]], dtype=torch.float64)
     dist.all_reduce(rays)
     if rank == 0:

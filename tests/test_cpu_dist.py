@@ -19,21 +19,25 @@ def test_partition_is_exact(pkg):
         partition.rank_frames(2, 2, 0, 1)
 
 
-@pytest.mark.parametrize("reduce_bands", [1, 3])
-def test_two_rank_sum_reduce_matches_sequential_mean(tmp_path, reduce_bands):
+@pytest.mark.parametrize("reduce_bands,launch_frames", [(1, 16), (3, 16), (3, 2)])
+def test_two_rank_sum_reduce_matches_sequential_mean(tmp_path, reduce_bands, launch_frames):
     """partition.render_partitioned (what bench.py runs on RCCL) under gloo with the oracle as renderer: one reduce of
-    the whole image, and the image finished in three row bands whose reduces overlap the next band's rendering."""
+    the whole image; the image finished in three row bands whose reduces overlap the next band's rendering; and the same
+    with a launch of two frames, so that the first two of the rank's three frames go out as a whole-image launch and only
+    the last launch's frame is rendered band by band."""
     out = tmp_path / "result.npz"
-    port = str(29641 + 10 * reduce_bands)
+    port = str(29641 + 10 * reduce_bands + launch_frames)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", port, os.path.join(ROOT, "tests", "dist_worker.py"), "3", str(out), "samples", str(reduce_bands)]
+           "--master-port", port, os.path.join(ROOT, "tests", "dist_worker.py"), "3", str(out), "samples", str(reduce_bands),
+           str(launch_frames)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = np.load(out)
     assert float(res["err"]) < 1e-6            # sum/N vs running mean: fp32 rounding only
     assert float(res["rays"]) == float(res["rays_seq"])   # every frame rendered exactly once
-    assert int(res["calls"]) == reduce_bands and bool(res["same_as_unbanded"])
+    head_calls = 1 if (reduce_bands > 1 and launch_frames < 3) else 0
+    assert int(res["calls"]) == reduce_bands + head_calls and bool(res["same_as_unbanded"])
 
 
 def test_two_rank_tile_partition_gathers_the_exact_image(tmp_path):

@@ -98,7 +98,13 @@ def test_frame0_full_size(pkg, oracle, gpu_ctx, scenes, name, flags_name):
     dict(frames=3, flags="wave+fix"),
     dict(frames=2, flags="mega"),
     dict(frames=2, flags="mega+fix"),
-    dict(frames=2, rays_per_pixel=3),
+    dict(frames=2, rays_per_pixel=3),     # samples of a pixel traced one after the other by its lane of the path kernel
+    dict(frames=5, rays_per_pixel=4),     # ... over more than one launch (16 staged samples per pixel and launch)
+    dict(frames=2, rays_per_pixel=2, flags="fix"),
+    dict(frames=2, rays_per_pixel=3, flags="sum", frame_stride=2, frame_base=0),
+    dict(frames=2, rays_per_pixel=2, frame_base=3),
+    dict(frames=1, rays_per_pixel=17),    # more samples than a launch stages: the megakernel takes it
+    dict(frames=2, rays_per_pixel=3, flags="mega"),
     dict(frames=1, ray_bounces=2),
     dict(frames=1, ray_bounces=1),
     dict(frames=1, ray_bounces=0),
