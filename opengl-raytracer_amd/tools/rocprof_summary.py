@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    for key in ("k_primary", "k_paths", "k_accumulate", "k_extend", "k_shade", "k_tail", "k_mega", "k_generate", "k_primary_hits", "k_normals", "k_selftest"):
+    for key in ("k_primary", "k_rebase", "k_paths", "k_accumulate", "k_extend", "k_shade", "k_tail", "k_mega", "k_generate", "k_primary_hits", "k_normals", "k_selftest"):
         if key in name:
             tail = name[name.index(key) + len(key):]
             t = ""
