@@ -800,3 +800,44 @@ def test_frame_loop_random_operation_sequences(pkg, gpu_ctx, scenes):
         assert np.array_equal(bits(results[0]), bits(results[1])), f"sequence {seed}"
     gpu_ctx.set_frames_ahead(8)
     plain.close()
+
+
+def _chain_scene(pkg, n=40):
+    """n triangles stacked behind one another in front of the default camera, under a hand-made tree that is one long chain:
+    every inner node has the nearer n-1-l triangles as its first child and the farthest remaining one as a leaf, so a ray
+    through the middle enters the chain first and leaves one pending entry per level."""
+    tri = np.zeros((n, 3, 3), dtype=np.float32)
+    for k in range(n):
+        s = 0.6 + 0.01 * k
+        tri[k] = ((-s, -s, 0.25 * k), (s, -s, 0.25 * k), (0.0, s, 0.25 * k))
+    nodes = np.zeros((2 * n - 1, 12), dtype=np.float32)
+
+    def put(i, lo, hi, leaf, a, b):
+        v = tri[lo:hi + 1].reshape(-1, 3)
+        nodes[i, 0:3], nodes[i, 4:7], nodes[i, 8:11] = v.min(0), v.max(0), (leaf, a, b)
+
+    for lvl in range(n - 1):
+        hi = n - 1 - lvl
+        put(2 * lvl, 0, hi, 0.0, 2 * (lvl + 1), 2 * lvl + 1)
+        put(2 * lvl + 1, hi, hi, 1.0, hi, hi)
+    put(2 * (n - 1), 0, 0, 1.0, 0, 0)
+    v = np.zeros((3, n, 4), dtype=np.float32)
+    v[:, :, :3] = tri.transpose(1, 0, 2)
+    return pkg.Scene(nodes, v[0], v[1], v[2], pkg.make_colours(7, n))
+
+
+def test_packet_that_outgrows_its_stack_hands_the_tile_back(pkg, oracle, gpu_ctx):
+    """A tile packet keeps 19 pending entries.  On a 39-level chain whose far child is pushed at every level the packets of the
+    middle tiles give up and flag their tile; the path kernel then traces those primary rays lane by lane (its own stack spills
+    to memory).  Pixels and counters must not show which way a tile went."""
+    scene = _chain_scene(pkg, 40)
+    cam = pkg.make_camera(pos=(0.0, 0.0, -0.8))
+    gpu_ctx.upload_scene(scene)
+    ids, t = gpu_ctx.primary_hits(cam, 200, 120)
+    ids_o, t_o = oracle.primary_hits(scene, cam, 200, 120)
+    assert np.array_equal(ids, ids_o) and np.array_equal(bits(t), bits(t_o))
+    assert (ids_o >= 0).mean() > 0.1 and (ids_o < 0).mean() > 0.1      # some tiles see the stack of triangles, some only sky
+    for extra in (0, pkg.RT_FLAG_FIX_INVDIR):
+        params = pkg.make_params(200, 120, frames=3, flags=extra)
+        want, cnt_o = oracle.render(scene, cam, params)
+        render_both_ways(pkg, gpu_ctx, cam, params, want, cnt_o, what=f"chain {extra}")
