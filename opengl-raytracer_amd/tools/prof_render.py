@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pipeline", default="paths", choices=["paths", "wavefront", "megakernel"])
     ap.add_argument("--fix-invdir", action="store_true")
+    ap.add_argument("--rays-per-pixel", type=int, default=1)
     ap.add_argument("--primary-only", action="store_true", help="time rt_primary_hits instead of full frames")
     ap.add_argument("--counters", action="store_true", help="render with RT_FLAG_COUNTERS and print the work counters")
     ap.add_argument("--per-frame", action="store_true", help="one rt_raytrace_frame call per frame (ping-pong buffers), as the reference's loop does")
@@ -76,8 +77,8 @@ def main():
         return
     if a.standalone:
         buf = pkg.DeviceBuffer(a.width * a.height * 16)
-        p = pkg.make_params(a.width, a.height, frames=a.frames, flags=flags)
-        ctx.render_device(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags), buf.ptr)
+        p = pkg.make_params(a.width, a.height, frames=a.frames, flags=flags, rays_per_pixel=a.rays_per_pixel)
+        ctx.render_device(cam, pkg.make_params(a.width, a.height, frames=a.warmup, flags=flags, rays_per_pixel=a.rays_per_pixel), buf.ptr)
         ctx.synchronize()
         ms = []
         for _ in range(a.standalone):
@@ -85,7 +86,7 @@ def main():
             ctx.render_device(cam, p, buf.ptr)
             ctx.synchronize()
             ms.append((time.perf_counter() - t0) * 1e3)
-        print(f"{a.pipeline} {a.scene} {a.width}x{a.height}: {a.standalone} synchronised calls of {a.frames} frames: "
+        print(f"{a.pipeline} {a.scene} {a.width}x{a.height}, {a.rays_per_pixel} spp: {a.standalone} synchronised calls of {a.frames} frames: "
               f"mean {sum(ms) / len(ms):.3f} min {min(ms):.3f} max {max(ms):.3f} ms per call (host clock)")
         buf.free()
         ctx.close()
