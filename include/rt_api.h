@@ -265,7 +265,8 @@ int rt_reset_counters(rt_context* ctx);
 /* enable != 0: bracket every kernel launch with HIP events on the context's stream (adds
  * event overhead; keep it off in throughput runs).  rt_kernel_times synchronises and
  * returns the summed milliseconds and launch counts per class since profiling was enabled
- * or last read, then clears them. */
+ * or last read, then clears them.  Launches of rt_raytrace_frame_noalloc are not bracketed
+ * (it creates no events), so they do not appear here. */
 int rt_set_profiling(rt_context* ctx, int enable);
 int rt_kernel_times(rt_context* ctx, float out_ms[RT_NUM_KERNEL_CLASSES],
                     uint32_t out_launches[RT_NUM_KERNEL_CLASSES]);
