@@ -93,6 +93,7 @@ struct CullPad {
 
 struct rt_context {
     int device = 0;
+    bool finite_boxes = false;   // every box of the current tree has finite corners (known from the upload's checks / the builder's reductions)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -151,6 +152,7 @@ struct rt_context {
     size_t num_recs = 0;          // inner-node records of the current scene
     float4* d_hitq = nullptr;
     uint32_t* d_hcount = nullptr;
+    uint32_t* d_pkctr = nullptr;               // k_primary's chunk counters: 8 x 16 words per staging slot
     size_t hitq_items = 0;        // (tile, frame) items the two buffers hold, all slots together
     uint2* d_pspill = nullptr;    // stack spill area, one copy per pipeline slot
     size_t pspill_entries = 0;
@@ -200,6 +202,10 @@ struct rt_context {
     int tune_overlap = 1;                      // 0: the batches of a call run one after the other on the context's stream (A/B runs)
     int tune_stagger = 1;                      // 1: the primary pass of a pipelined launch waits for the previous launch's (launch_paths_batch)
     int tune_queue_blocks = 1;                 // workgroups per CU of a pipelined path launch that starts from k_primary's hit queues
+    int tune_last_blocks = PT_BLOCKS_PER_CU;   // ... of the last such launch of a call (no primary pass runs next to it)
+    int tune_primary_chunk = 4;                // items a wave of k_primary takes per grab
+    int tune_primary_blocks = PK_BLOCKS_PER_CU;  // workgroups per CU of k_primary's grid
+    int tune_signed_slabs = 1;                 // k_primary: sign-specific slab tests where a packet's rays allow them (0: A/B runs)
     int tune_packets = 1;                      // primary rays traced tile by tile: 1 by rule (use_packets), 0 never, 2 always (A/B runs)
 
     unsigned long long* d_counters = nullptr;
@@ -576,6 +582,9 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
     a.hits = nullptr;
     a.rnodes = nullptr;
+    a.pk_ctr = nullptr;
+    a.pk_chunk = 1;
+    a.finite_boxes = c->finite_boxes && c->tune_signed_slabs ? 1u : 0u;
     a.hitq = nullptr;
     a.hcount = nullptr;
     a.samples = nullptr;
@@ -601,17 +610,21 @@ static void paths_thresholds(const rt_context* c, bool fix, int pmode, PathsArgs
 }
 
 static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsArgs& args, bool count, bool fix, int pmode, bool overlapped,
-                           hipStream_t st) {
+                           hipStream_t st, bool followed = true) {
     PathsArgs a = args;
     paths_thresholds(c, fix, pmode, a);
     // (the spill area is sized for the full grid; a smaller grid uses a prefix of it)
     // Workgroups per CU.  A launch that has the chip to itself fills it (2 x 16 waves per CU).  Pipelined launches share it:
     // a single-frame launch takes one workgroup per CU, so that two consecutive frames are resident side by side; so does a
-    // launch that starts from k_primary's hit queues, which leaves half of every CU's LDS and wave slots to the next
-    // launch's primary pass -- that pass is dense arithmetic, this kernel waits on memory most of the time, and next to each
-    // other they fill each other's gaps (dragon80k, bench.py --steps 20 / 128: 11.8 -> 12.1 / 12.0 -> 12.4 Grays/s).
-    const int per_cu = !overlapped ? PT_BLOCKS_PER_CU : a.num_frames == 1 ? c->tune_frame_blocks : pmode == PM_QUEUE ? c->tune_queue_blocks
-                                                                                                                 : c->tune_batch_blocks;
+    // launch that starts from k_primary's hit queues AND is followed by another launch of the same call, which leaves half
+    // of every CU's LDS and wave slots to that launch's primary pass -- that pass is dense arithmetic, this kernel waits on
+    // memory most of the time, and next to each other they fill each other's gaps (dragon80k, bench.py --steps 20 / 128:
+    // 11.8 -> 12.1 / 12.0 -> 12.4 Grays/s).  The last launch of a call has no primary pass next to it: with two workgroups
+    // per CU a 16-frame queue launch alone takes 2.28 instead of 2.70 ms.
+    const int per_cu = !overlapped                                ? PT_BLOCKS_PER_CU
+                       : a.num_frames == 1                        ? c->tune_frame_blocks
+                       : pmode == PM_QUEUE                        ? (followed ? c->tune_queue_blocks : c->tune_last_blocks)
+                                                                  : c->tune_batch_blocks;
     dim3 grid(c->num_cus * per_cu), blk(PT_BLOCK);
 #define PATHS(C_, F_, M_) hipLaunchKernelGGL((k_paths<C_, F_, M_>), grid, blk, 0, st, c->sc, dc, a)
     if (pmode == PM_PRIMARY) {  // no bounces in this pass: invDir handling does not matter
@@ -686,7 +699,10 @@ static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& 
     const size_t share = c->hitq_items / RT_LANES;
     a.hitq = c->d_hitq + (size_t)slot * share * 64;
     a.hcount = c->d_hcount + (size_t)slot * share;
-    dim3 grid(c->num_cus * PK_BLOCKS_PER_CU), blk(PK_BLOCK);
+    a.pk_ctr = c->d_pkctr + (size_t)slot * 128;
+    a.pk_chunk = (uint32_t)c->tune_primary_chunk;
+    (void)hipMemsetAsync(a.pk_ctr, 0, 128 * sizeof(uint32_t), st);
+    dim3 grid(c->num_cus * c->tune_primary_blocks), blk(PK_BLOCK);
     if (count)
         hipLaunchKernelGGL((k_primary<true>), grid, blk, 0, st, c->sc, dc, a);
     else
@@ -761,7 +777,7 @@ static int launch_k_primary_pipelined(rt_context* c, const DCamera& dc, PathsArg
 // (see rt_context::lane_stream) and overlaps with the previous launch's; the accumulate kernel, which carries the
 // frame-to-frame dependency, goes to the context's stream.
 static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
-                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined) {
+                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined, bool followed = true) {
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     ahead_discard(c);  // this launch takes a staging slot of its own
@@ -800,7 +816,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     }
     {
         LaunchTimer lt(c, RT_K_PATHS);
-        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : packets ? PM_QUEUE : a.rpp > 1u ? PM_MULTI : PM_TRACE, pipelined, pst);
+        launch_k_paths(c, dc, a, count, fix, reuse ? PM_REUSE : packets ? PM_QUEUE : a.rpp > 1u ? PM_MULTI : PM_TRACE, pipelined, pst, followed);
     }
     HIPCHK(c, hipGetLastError());
     if (pipelined) {
@@ -977,6 +993,11 @@ int rt_create(int device_id, rt_context** out_ctx) {
             return rc;
         }
     }
+    if ((e = hipMalloc(&c->d_pkctr, (size_t)RT_LANES * 128 * sizeof(uint32_t))) != hipSuccess) {
+        int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
+        rt_destroy(c);
+        return rc;
+    }
 #ifdef RT_TUNABLES
     // Tuning builds only (librt_hip_tune.so, used by tools/ and by the tests that cross-check a non-default variant): the
     // scheduling parameters can be overridden from the environment, read once here.  The shipped library reads none.
@@ -995,6 +1016,10 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_OVERLAP")) c->tune_overlap = atoi(e);
     if (const char* e = getenv("RT_TUNE_STAGGER")) c->tune_stagger = atoi(e);
     if (const char* e = getenv("RT_TUNE_QUEUE_BLOCKS")) c->tune_queue_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_PRIMARY_CHUNK")) c->tune_primary_chunk = atoi(e);
+    if (const char* e = getenv("RT_TUNE_PRIMARY_BLOCKS")) c->tune_primary_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_SIGNED_SLABS")) c->tune_signed_slabs = atoi(e);
+    if (const char* e = getenv("RT_TUNE_LAST_BLOCKS")) c->tune_last_blocks = atoi(e);
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("RT_BUILD_SMALL_MAX")) c->build_small_max = atoi(e) == 128 ? 128 : 256;
     if (const char* e = getenv("RT_BUILD_TINY")) { int v = atoi(e); c->build_tiny = v == 0 ? 0 : (v == 4 ? 4 : 8); }
@@ -1009,6 +1034,9 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->tune_frame_blocks = clamp(c->tune_frame_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_batch_blocks = clamp(c->tune_batch_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_queue_blocks = clamp(c->tune_queue_blocks, 1, PT_BLOCKS_PER_CU);
+    c->tune_last_blocks = clamp(c->tune_last_blocks, 1, PT_BLOCKS_PER_CU);
+    c->tune_primary_blocks = clamp(c->tune_primary_blocks, 1, PK_BLOCKS_PER_CU);
+    c->tune_primary_chunk = clamp(c->tune_primary_chunk, 1, 64);
     c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
 #endif
     hipDeviceProp_t prop;
@@ -1033,6 +1061,7 @@ int rt_destroy(rt_context* c) {
     }
     free_scene(c);
     free_buffers(c);
+    dfree(c->d_pkctr);
     if (c->phits_ready) (void)hipEventDestroy(c->phits_ready);
     for (void* p : c->ws_ptr)
         if (p) (void)hipFree(p);
@@ -1284,6 +1313,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
         double diag2 = 0.0;
         for (int k = 0; k < 3; k++) diag2 += ((double)s->nodes[4 + k] - s->nodes[k]) * ((double)s->nodes[4 + k] - s->nodes[k]);
         c->cull = nested ? cull_pad_of(std::sqrt(diag2), edge_prod_max, edge_max, c->tune_cull_reach) : CullPad();
+        c->finite_boxes = nested && std::isfinite(diag2);   // nested: every box inside its parent's, comparisons false on a NaN
     }
     c->has_scene = true;
     // a deeper tree may need a larger spill area: force re-allocation on the next render
@@ -1464,6 +1494,7 @@ static int build_core(rt_context* c) {
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
     c->cull = built_cull_pad(rlo, rhi, edge_max, c->tune_cull_reach);
+    c->finite_boxes = std::isfinite(edge_max[0]) && std::isfinite(edge_max[1]) && std::isfinite(rlo.x + rlo.y + rlo.z + rhi.x + rhi.y + rhi.z);
     c->sc.root_ref = num_nodes == 1 ? ~0 : 0;  // a single leaf starts at triangle 0; otherwise the root owns record 0
     c->sc.num_tris = nf;
     c->num_tris = nf;
@@ -1554,6 +1585,7 @@ int rt_refit_scene_device(rt_context* c, const float* d_vertices) {
     bd.ref_valid = false;
     c->phits_valid = false;
     c->cull = built_cull_pad(rlo, rhi, edge_max, c->tune_cull_reach);
+    c->finite_boxes = std::isfinite(edge_max[0]) && std::isfinite(edge_max[1]) && std::isfinite(rlo.x + rlo.y + rlo.z + rhi.x + rhi.y + rhi.z);
     c->sc.rmin[0] = rlo.x; c->sc.rmin[1] = rlo.y; c->sc.rmin[2] = rlo.z;
     c->sc.rmax[0] = rhi.x; c->sc.rmax[1] = rhi.y; c->sc.rmax[2] = rhi.z;
     return RT_OK;
@@ -1777,7 +1809,12 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     const uint32_t batch = paths_batch((size_t)p->width * p->height) / p->rays_per_pixel;  // frames x samples staged per launch
     for (uint32_t f = 0; f < p->frames; f += batch) {
         uint32_t n = p->frames - f < batch ? p->frames - f : batch;
-        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, true);
+        // "followed": another launch of this call comes after this one, or this one is a short remainder that starts while
+        // its predecessor still drains (workgroups that start late carry a full share of the items: bench.py --steps 20,
+        // 16 + 4 frames: 4.70 ms with one workgroup per CU for the remainder, 4.75 with two; 16, 64 steps: 4.43 -> 4.01,
+        // 15.6 -> 15.1 ms with two for the last full launch)
+        rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, true,
+                                f + n < p->frames || (f > 0 && 2u * n <= batch));
         if (rc != RT_OK) return rc;
     }
     return RT_OK;

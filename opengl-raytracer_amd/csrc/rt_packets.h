@@ -27,7 +27,9 @@
 
 #define PK_BLOCK 256                 // 4 waves per workgroup
 #define PK_BLOCKS_PER_CU 8           // 32 waves per CU, 8 per SIMD (needs <= 64 VGPRs and 20 KiB of LDS per workgroup)
+#ifndef PK_STACK
 #define PK_STACK 19                  // packet-stack entries (a 256-byte row of per-lane distances each, in LDS)
+#endif
 #define PK_TRACE_ITEM 0xffffffffu
 
 typedef float pk_f4 __attribute__((ext_vector_type(4)));
@@ -59,275 +61,360 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
 // per-lane distances per entry.  The slab test, the triangle test (with the correctly rounded division) and their
 // instruction order are the compiler's own output for box_dist / tri_dist_flat, so results are bit-identical.
 // `nodes` are the launch's rebased records (k_rebase: box corners minus the common ray origin); the triangle test still
-// needs the origin.  Registers s36-s91 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
-__device__ __forceinline__ bool pk_traverse(unsigned long long nodes, unsigned long long tris, int root, unsigned long long in0,
-                                            rt_vec3 o, rt_vec3 d, rt_vec3 inv, uint32_t lrow, float& best, int& best_id) {
-    int gave;
-    asm volatile(
-        "s_mov_b64 s[74:75], exec\n\t"
-        "s_mov_b32 s90, 0x38d1b717\n\t"            // RT_EPS
-        "v_mov_b32_e32 v60, 0x7f800000\n\t"        // +inf
-        "s_mov_b32 s71, 0\n\t"                     // stack pointer
-        "s_mov_b32 %[gave], 0\n\t"
-        "s_mov_b32 s70, %[root]\n\t"               // current node
-        "s_and_b64 exec, s[74:75], %[in0]\n\t"
-        "s_cbranch_execz Ldone%=\n"
-        "Lnode%=:\n\t"
-        "s_cmp_lt_i32 s70, 0\n\t"
-        "s_cbranch_scc1 Lleaf%=\n\t"
-        // ---- inner node: record = (c1.min c1.max c2.min c2.max ref1 ref2 - -)
-        "s_lshl_b32 s72, s70, 6\n\t"
-        "s_load_dwordx16 s[36:51], %[nodes], s72\n\t"
+// needs the origin.  Registers s36-s77 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
+// The text comes in three pieces -- up to the arrival of an inner node's record, the two slab tests (which leave the
+// distances to child 1 / child 2 in v51 / v52: the reference's value when the ray meets the box, +inf otherwise), and
+// everything after them -- and PK_DEFINE_TRAVERSE makes one function per form of the slab tests.
+#define PK_STR2(x) #x
+#define PK_STR(x) PK_STR2(x)
+// diagnostic builds: PK_PAD_V vector / PK_PAD_S scalar no-ops per inner-node visit, to measure what an instruction there costs
+#ifdef PK_PAD_V
+#define PK_ASM_PAD_V ".rept " PK_STR(PK_PAD_V) "\n\tv_nop\n\t.endr\n\t"
+#else
+#define PK_ASM_PAD_V ""
+#endif
+#ifdef PK_PAD_S
+#define PK_ASM_PAD_S ".rept " PK_STR(PK_PAD_S) "\n\ts_nop 0\n\t.endr\n\t"
+#else
+#define PK_ASM_PAD_S ""
+#endif
+
+#define PK_ASM_HEAD \
+        "s_mov_b64 s[74:75], exec\n\t"                                                                                 \
+        "s_mov_b32 s76, 0x38d1b717\n\t" /* RT_EPS */                                                                   \
+        "v_mov_b32_e32 v60, 0x7f800000\n\t" /* +inf */                                                                 \
+        "s_mov_b32 s71, 0\n\t" /* stack pointer */                                                                     \
+        "s_mov_b32 %[gave], 0\n\t"                                                                                     \
+        "s_mov_b32 s70, %[root]\n\t" /* current node */                                                                \
+        "s_and_b64 exec, s[74:75], %[in0]\n\t"                                                                         \
+        "s_cbranch_execz Ldone%=\n"                                                                                    \
+        "Lnode%=:\n\t"                                                                                                 \
+        "s_cmp_lt_i32 s70, 0\n\t"                                                                                      \
+        "s_cbranch_scc1 Lleaf%=\n\t"                                                                                   \
+        /* ---- inner node: record = (c1.min c1.max c2.min c2.max ref1 ref2 - -) */                                    \
+        "s_lshl_b32 s72, s70, 6\n\t"                                                                                   \
+        "s_load_dwordx16 s[36:51], %[nodes], s72\n\t"                                                                  \
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_f32_e32 v40, s36, %[ix]\n\t"      // the record holds (corner - origin) already: k_rebase
-        "v_mul_f32_e32 v41, s37, %[iy]\n\t"
-        "v_mul_f32_e32 v42, s38, %[iz]\n\t"
-        "v_mul_f32_e32 v43, s39, %[ix]\n\t"
-        "v_mul_f32_e32 v44, s40, %[iy]\n\t"
-        "v_mul_f32_e32 v45, s41, %[iz]\n\t"
-        "v_min_f32_e32 v46, v40, v43\n\t"
-        "v_min_f32_e32 v47, v41, v44\n\t"
-        "v_min_f32_e32 v48, v42, v45\n\t"
-        "v_max_f32_e32 v40, v40, v43\n\t"
-        "v_max_f32_e32 v41, v41, v44\n\t"
-        "v_max_f32_e32 v42, v42, v45\n\t"
-        "v_max3_f32 v49, v46, v47, v48\n\t"        // tNear
-        "v_min3_f32 v50, v40, v41, v42\n\t"        // tFar
-        "v_cmp_lt_f32_e64 s[80:81], s90, v49\n\t"  // EPS < tNear
-        "v_mul_f32_e32 v40, s42, %[ix]\n\t"
-        "v_mul_f32_e32 v41, s43, %[iy]\n\t"
-        "v_mul_f32_e32 v42, s44, %[iz]\n\t"
-        "v_mul_f32_e32 v43, s45, %[ix]\n\t"
-        "v_mul_f32_e32 v44, s46, %[iy]\n\t"
-        "v_mul_f32_e32 v45, s47, %[iz]\n\t"
-        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"       // tFar >= tNear
-        "v_cmp_lt_f32_e64 s[78:79], s90, v50\n\t"  // EPS < tFar
-        "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"
-        "v_min_f32_e32 v46, v40, v43\n\t"
-        "v_min_f32_e32 v47, v41, v44\n\t"
-        "v_min_f32_e32 v48, v42, v45\n\t"
-        "v_max_f32_e32 v40, v40, v43\n\t"
-        "v_max_f32_e32 v41, v41, v44\n\t"
-        "v_max_f32_e32 v42, v42, v45\n\t"
-        "s_and_b64 vcc, vcc, s[78:79]\n\t"
-        "v_max3_f32 v49, v46, v47, v48\n\t"
-        "v_min3_f32 v50, v40, v41, v42\n\t"
-        "v_cndmask_b32_e32 v51, v60, v51, vcc\n\t"  // d1 = hit ? (tNear > EPS ? tNear : 0) : inf
-        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"
-        "v_cmp_lt_f32_e64 s[78:79], s90, v50\n\t"
-        "v_cmp_lt_f32_e64 s[80:81], s90, v49\n\t"
-        "s_and_b64 vcc, vcc, s[78:79]\n\t"
-        "s_nop 0\n\t"
-        "v_cndmask_b32_e64 v52, 0, v49, s[80:81]\n\t"
-        "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t"  // d2
-        // who wants which child, and in which order (raytrace.glsl:173-190)
-        "v_cmp_lt_f32_e64 s[52:53], v51, %[best]\n\t"   // W1
-        "v_cmp_lt_f32_e64 s[54:55], v52, %[best]\n\t"   // W2
-        "v_cmp_lt_f32_e64 s[56:57], v51, v52\n\t"       // LT: child 1 first
-        "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t"    // both
-        "s_and_b64 s[60:61], s[58:59], s[56:57]\n\t"    // both, child 1 first
-        "s_andn2_b64 s[62:63], s[58:59], s[56:57]\n\t"  // both, child 2 first
-        "s_bcnt1_i32_b64 s72, s[60:61]\n\t"
-        "s_bcnt1_i32_b64 s73, s[62:63]\n\t"
-        "s_cmp_gt_u32 s72, s73\n\t"                     // scc: the wave takes child 1 first
-        "s_cselect_b64 s[64:65], s[52:53], s[54:55]\n\t"  // lanes of the first child
-        "s_cselect_b64 s[66:67], s[54:55], s[52:53]\n\t"  // lanes of the second child
-        "s_cselect_b32 s68, s48, s49\n\t"               // first child
-        "s_cselect_b32 s69, s49, s48\n\t"               // second child
-        "s_cselect_b64 s[62:63], s[62:63], s[60:61]\n\t"  // dissenters
-        "s_cselect_b64 vcc, -1, 0\n\t"
-        "v_cndmask_b32_e32 v53, v52, v51, vcc\n\t"      // distances to the first ...
-        "v_cndmask_b32_e32 v54, v51, v52, vcc\n\t"      // ... and to the second child
-        "s_andn2_b64 s[64:65], s[64:65], s[62:63]\n\t"
-        "s_cbranch_scc0 Lswap%=\n\t"
-        "s_cmp_gt_u32 s71, %[room]\n\t"
-        "s_cbranch_scc1 Lgiveup%=\n\t"
-        "s_cmp_eq_u64 s[62:63], 0\n\t"
-        "s_cbranch_scc1 Lnodis%=\n\t"
-        "s_mov_b32 m0, s71\n\t"                          // the dissenters come back for the first child after the second
-        "s_nop 0\n\t"
-        "v_writelane_b32 v57, s68, m0\n\t"
-        "v_writelane_b32 v58, s62, m0\n\t"
-        "v_writelane_b32 v59, s63, m0\n\t"
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"
-        "ds_write_b32 v55, v53\n\t"
-        "s_add_i32 s71, s71, 1\n"
-        "Lnodis%=:\n\t"
-        "s_cmp_eq_u64 s[66:67], 0\n\t"
-        "s_cbranch_scc1 Lgo%=\n\t"
-        "s_mov_b32 m0, s71\n\t"
-        "s_nop 0\n\t"
-        "v_writelane_b32 v57, s69, m0\n\t"
-        "v_writelane_b32 v58, s66, m0\n\t"
-        "v_writelane_b32 v59, s67, m0\n\t"
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"
-        "ds_write_b32 v55, v54\n\t"
-        "s_add_i32 s71, s71, 1\n"
-        "Lgo%=:\n\t"
-        "s_mov_b32 s70, s68\n\t"
-        "s_mov_b64 exec, s[64:65]\n\t"
-        "s_branch Lnode%=\n"
-        "Lswap%=:\n\t"                                    // nobody enters the first child (then nobody dissents): on to the second
-        "s_cmp_eq_u64 s[66:67], 0\n\t"
-        "s_cbranch_scc1 Lpop%=\n\t"
-        "s_mov_b32 s70, s69\n\t"
-        "s_mov_b64 exec, s[66:67]\n\t"
-        "s_branch Lnode%=\n"
-        // ---- leaf: triangle records (a flags)(e1 id)(e2 -), the last one of the leaf has flag bit 0
-        "Lleaf%=:\n\t"
-        "s_cmp_eq_u32 s70, 0x80000001\n\t"
-        "s_cbranch_scc1 Lpop%=\n\t"
-        "s_not_b32 s72, s70\n\t"
-        "s_lshl_b32 s72, s72, 6\n"
-        "Ltri%=:\n\t"
-        "s_load_dwordx8 s[36:43], %[tris], s72\n\t"
-        "s_add_u32 s73, s72, 32\n\t"
-        "s_load_dwordx4 s[44:47], %[tris], s73\n\t"
-        "s_add_u32 s72, s72, 64\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_f32_e32 v40, s46, %[dy]\n\t"
-        "v_mul_f32_e32 v41, s45, %[dz]\n\t"
-        "v_mul_f32_e32 v42, s44, %[dz]\n\t"
-        "v_mul_f32_e32 v43, s46, %[dx]\n\t"
-        "v_mul_f32_e32 v44, s45, %[dx]\n\t"
-        "v_mul_f32_e32 v45, s44, %[dy]\n\t"
-        "v_sub_f32_e32 v40, v40, v41\n\t"               // p = cross(d, e2)
-        "v_sub_f32_e32 v41, v42, v43\n\t"
-        "v_sub_f32_e32 v42, v44, v45\n\t"
-        "v_subrev_f32_e32 v43, s36, %[ox]\n\t"          // s = o - a
-        "v_subrev_f32_e32 v44, s37, %[oy]\n\t"
-        "v_subrev_f32_e32 v45, s38, %[oz]\n\t"
-        "v_mul_f32_e32 v46, s40, v40\n\t"
-        "v_mul_f32_e32 v47, s41, v41\n\t"
-        "v_mul_f32_e32 v48, s42, v42\n\t"
-        "v_mul_f32_e32 v40, v43, v40\n\t"
-        "v_mul_f32_e32 v41, v44, v41\n\t"
-        "v_mul_f32_e32 v42, v45, v42\n\t"
-        "v_mul_f32_e32 v49, s42, v44\n\t"
-        "v_mul_f32_e32 v50, s41, v45\n\t"
-        "v_mul_f32_e32 v45, s40, v45\n\t"
-        "v_mul_f32_e32 v51, s42, v43\n\t"
-        "v_mul_f32_e32 v43, s41, v43\n\t"
-        "v_mul_f32_e32 v44, s40, v44\n\t"
-        "v_add_f32_e32 v46, v46, v47\n\t"
-        "v_add_f32_e32 v40, v40, v41\n\t"
-        "v_sub_f32_e32 v41, v49, v50\n\t"               // q = cross(s, e1)
-        "v_sub_f32_e32 v45, v45, v51\n\t"
-        "v_sub_f32_e32 v43, v43, v44\n\t"
-        "v_add_f32_e32 v44, v48, v46\n\t"               // det = dot(e1, p)
-        "v_add_f32_e32 v40, v42, v40\n\t"               // dot(s, p)
-        "v_mul_f32_e32 v42, %[dx], v41\n\t"
-        "v_mul_f32_e32 v46, %[dy], v45\n\t"
-        "v_mul_f32_e32 v41, s44, v41\n\t"
-        "v_mul_f32_e32 v45, s45, v45\n\t"
-        "v_div_scale_f32 v48, s[78:79], v44, v44, 1.0\n\t"   // inv_det = 1 / det, correctly rounded
-        "v_add_f32_e32 v41, v41, v45\n\t"
-        "v_rcp_f32_e32 v45, v48\n\t"
-        "v_mul_f32_e32 v47, %[dz], v43\n\t"
-        "v_mul_f32_e32 v43, s46, v43\n\t"
-        "v_add_f32_e32 v41, v43, v41\n\t"               // dot(e2, q)
-        "v_fma_f32 v43, -v48, v45, 1.0\n\t"
-        "v_div_scale_f32 v49, vcc, 1.0, v44, 1.0\n\t"
-        "v_fmac_f32_e32 v45, v43, v45\n\t"
-        "v_mul_f32_e32 v43, v49, v45\n\t"
-        "v_add_f32_e32 v42, v42, v46\n\t"
-        "v_fma_f32 v46, -v48, v43, v49\n\t"
-        "v_fmac_f32_e32 v43, v46, v45\n\t"
-        "v_fma_f32 v46, -v48, v43, v49\n\t"
-        "v_div_fmas_f32 v43, v46, v45, v43\n\t"
-        "v_div_fixup_f32 v43, v43, v44, 1.0\n\t"
-        "v_add_f32_e32 v42, v47, v42\n\t"               // dot(d, q)
-        "v_mul_f32_e32 v40, v40, v43\n\t"               // u
-        "s_and_b32 s91, s39, 1\n\t"
-        "v_mul_f32_e32 v42, v42, v43\n\t"               // v
-        "v_mul_f32_e32 v41, v41, v43\n\t"               // t
-        "v_cmp_gt_f32_e32 vcc, 0, v40\n\t"
-        "v_cmp_gt_f32_e64 s[80:81], |v40|, s90\n\t"
-        "v_add_f32_e32 v43, -1.0, v40\n\t"
-        "v_mov_b32_e32 v61, s43\n\t"
-        "v_cmp_lt_f32_e64 s[82:83], |v44|, s90\n\t"
-        "v_cmp_lt_f32_e64 s[84:85], 1.0, v40\n\t"
-        "v_add_f32_e32 v40, v40, v42\n\t"
-        "s_and_b64 s[80:81], vcc, s[80:81]\n\t"
-        "v_cmp_gt_f32_e64 s[86:87], |v43|, s90\n\t"
-        "v_cmp_gt_f32_e64 s[88:89], 0, v42\n\t"
-        "v_cmp_gt_f32_e64 s[52:53], |v42|, s90\n\t"
-        "v_cmp_lt_f32_e32 vcc, 1.0, v40\n\t"
-        "v_add_f32_e32 v40, -1.0, v40\n\t"
-        "s_or_b64 s[82:83], s[82:83], s[80:81]\n\t"
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
-        "s_and_b64 s[88:89], s[88:89], s[52:53]\n\t"
-        "v_cmp_gt_f32_e64 s[80:81], |v40|, s90\n\t"
-        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"
-        "s_and_b64 s[82:83], vcc, s[80:81]\n\t"
-        "s_or_b64 s[84:85], s[88:89], s[84:85]\n\t"
-        "v_cmp_nlt_f32_e64 s[54:55], s90, v41\n\t"
-        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"
-        "s_or_b64 vcc, s[54:55], s[84:85]\n\t"
-        "v_cndmask_b32_e32 v40, v41, v60, vcc\n\t"      // rejected ? inf : t
-        "v_cmp_lt_f32_e32 vcc, v40, %[best]\n\t"
-        "s_cmp_eq_u32 s91, 0\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32_e32 %[bid], %[bid], v61, vcc\n\t"
-        "v_cndmask_b32_e32 %[best], %[best], v40, vcc\n\t"
-        "s_cbranch_scc1 Ltri%=\n"
-        // ---- next stack entry that still has a lane whose distance to it is below its closest hit (raytrace.glsl:151)
-        "Lpop%=:\n\t"
-        "s_cmp_eq_u32 s71, 0\n\t"
-        "s_cbranch_scc1 Ldone%=\n\t"
-        "s_add_i32 s71, s71, -1\n\t"
-        "s_nop 0\n\t"
-        "v_readlane_b32 s78, v58, s71\n\t"
-        "v_readlane_b32 s79, v59, s71\n\t"
-        "s_mov_b64 exec, s[78:79]\n\t"
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"
-        "ds_read_b32 v56, v55\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_lt_f32_e32 vcc, v56, %[best]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "s_cbranch_scc0 Lpop%=\n\t"
-        "v_readlane_b32 s70, v57, s71\n\t"
-        "s_branch Lnode%=\n"
-        "Lgiveup%=:\n\t"
-        "s_mov_b32 %[gave], 1\n"
-        "Ldone%=:\n\t"
+
+#define PK_ASM_SLAB_ANY \
+        "v_mul_f32_e32 v40, s36, %[ix]\n\t" /* the record holds (corner - origin) already: k_rebase */                 \
+        "v_mul_f32_e32 v41, s37, %[iy]\n\t"                                                                            \
+        "v_mul_f32_e32 v42, s38, %[iz]\n\t"                                                                            \
+        "v_mul_f32_e32 v43, s39, %[ix]\n\t"                                                                            \
+        "v_mul_f32_e32 v44, s40, %[iy]\n\t"                                                                            \
+        "v_mul_f32_e32 v45, s41, %[iz]\n\t"                                                                            \
+        "v_min_f32_e32 v46, v40, v43\n\t"                                                                              \
+        "v_min_f32_e32 v47, v41, v44\n\t"                                                                              \
+        "v_min_f32_e32 v48, v42, v45\n\t"                                                                              \
+        "v_max_f32_e32 v40, v40, v43\n\t"                                                                              \
+        "v_max_f32_e32 v41, v41, v44\n\t"                                                                              \
+        "v_max_f32_e32 v42, v42, v45\n\t"                                                                              \
+        "v_max3_f32 v49, v46, v47, v48\n\t" /* tNear */                                                                \
+        "v_min3_f32 v50, v40, v41, v42\n\t" /* tFar */                                                                 \
+        "v_cmp_lt_f32_e64 s[80:81], s76, v49\n\t" /* EPS < tNear */                                                    \
+        "v_mul_f32_e32 v40, s42, %[ix]\n\t"                                                                            \
+        "v_mul_f32_e32 v41, s43, %[iy]\n\t"                                                                            \
+        "v_mul_f32_e32 v42, s44, %[iz]\n\t"                                                                            \
+        "v_mul_f32_e32 v43, s45, %[ix]\n\t"                                                                            \
+        "v_mul_f32_e32 v44, s46, %[iy]\n\t"                                                                            \
+        "v_mul_f32_e32 v45, s47, %[iz]\n\t"                                                                            \
+        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t" /* tFar >= tNear */                                                       \
+        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t" /* EPS < tFar */                                                     \
+        "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"                                                                  \
+        "v_min_f32_e32 v46, v40, v43\n\t"                                                                              \
+        "v_min_f32_e32 v47, v41, v44\n\t"                                                                              \
+        "v_min_f32_e32 v48, v42, v45\n\t"                                                                              \
+        "v_max_f32_e32 v40, v40, v43\n\t"                                                                              \
+        "v_max_f32_e32 v41, v41, v44\n\t"                                                                              \
+        "v_max_f32_e32 v42, v42, v45\n\t"                                                                              \
+        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
+        "v_max3_f32 v49, v46, v47, v48\n\t"                                                                            \
+        "v_min3_f32 v50, v40, v41, v42\n\t"                                                                            \
+        "v_cndmask_b32_e32 v51, v60, v51, vcc\n\t" /* d1 = hit ? (tNear > EPS ? tNear : 0) : inf */                    \
+        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"                                                                           \
+        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t"                                                                      \
+        "v_cmp_lt_f32_e64 s[80:81], s76, v49\n\t"                                                                      \
+        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
+        "s_nop 0\n\t"                                                                                                  \
+        "v_cndmask_b32_e64 v52, 0, v49, s[80:81]\n\t"                                                                  \
+        "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t" /* d2 */
+
+// The slab tests for a packet whose rays all point the same way along every axis (and have finite reciprocals), on a tree
+// whose boxes are finite: with 1/d > 0 the product with the box's lower corner is the smaller of the two (rounding is
+// monotonic, and lo - o <= hi - o), with 1/d < 0 the one with the upper corner, so the min and max of raytrace.glsl:117-118
+// are known in advance and 12 of the 38 vector instructions go away.  Same values, hence same distances, as the general
+// form (a zero may differ in sign where both products are zeros; the distance handed on is then the literal 0 either way).
+// n1x = the register holding child 1's NEAR plane along x for this direction, f1x its far plane, and so on.
+#define PK_ASM_SLAB_SIGNED(n1x, f1x, n2x, f2x, n1y, f1y, n2y, f2y, n1z, f1z, n2z, f2z) \
+        "v_mul_f32_e32 v40, " n1x ", %[ix]\n\t"                                                                        \
+        "v_mul_f32_e32 v41, " n1y ", %[iy]\n\t"                                                                        \
+        "v_mul_f32_e32 v42, " n1z ", %[iz]\n\t"                                                                        \
+        "v_mul_f32_e32 v43, " f1x ", %[ix]\n\t"                                                                        \
+        "v_mul_f32_e32 v44, " f1y ", %[iy]\n\t"                                                                        \
+        "v_mul_f32_e32 v45, " f1z ", %[iz]\n\t"                                                                        \
+        "v_max3_f32 v49, v40, v41, v42\n\t" /* tNear of child 1 */                                                     \
+        "v_min3_f32 v50, v43, v44, v45\n\t" /* tFar */                                                                 \
+        "v_mul_f32_e32 v46, " n2x ", %[ix]\n\t"                                                                        \
+        "v_mul_f32_e32 v47, " n2y ", %[iy]\n\t"                                                                        \
+        "v_mul_f32_e32 v48, " n2z ", %[iz]\n\t"                                                                        \
+        "v_mul_f32_e32 v40, " f2x ", %[ix]\n\t"                                                                        \
+        "v_mul_f32_e32 v41, " f2y ", %[iy]\n\t"                                                                        \
+        "v_mul_f32_e32 v42, " f2z ", %[iz]\n\t"                                                                        \
+        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"                                                                           \
+        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t"                                                                      \
+        "v_cmp_lt_f32_e64 s[80:81], s76, v49\n\t"                                                                      \
+        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
+        "v_max3_f32 v53, v46, v47, v48\n\t" /* tNear of child 2 */                                                     \
+        "v_min3_f32 v54, v40, v41, v42\n\t"                                                                            \
+        "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"                                                                  \
+        "v_cndmask_b32_e32 v51, v60, v51, vcc\n\t" /* d1 */                                                            \
+        "v_cmp_ge_f32_e32 vcc, v54, v53\n\t"                                                                           \
+        "v_cmp_lt_f32_e64 s[78:79], s76, v54\n\t"                                                                      \
+        "v_cmp_lt_f32_e64 s[80:81], s76, v53\n\t"                                                                      \
+        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
+        "s_nop 0\n\t"                                                                                                  \
+        "v_cndmask_b32_e64 v52, 0, v53, s[80:81]\n\t"                                                                  \
+        "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t" /* d2 */
+#define PK_ASM_SLAB_EXPAND(...) PK_ASM_SLAB_SIGNED(__VA_ARGS__)
+#define PK_XP "s36", "s39", "s42", "s45"   /* rays go up the x axis: near planes are the boxes' lower x, far planes the upper */
+#define PK_XN "s39", "s36", "s45", "s42"
+#define PK_YP "s37", "s40", "s43", "s46"
+#define PK_YN "s40", "s37", "s46", "s43"
+#define PK_ZP "s38", "s41", "s44", "s47"
+#define PK_ZN "s41", "s38", "s47", "s44"
+
+#define PK_ASM_TAIL \
+        /* who wants which child, and in which order (raytrace.glsl:173-190) */                                        \
+        "v_cmp_lt_f32_e64 s[52:53], v51, %[best]\n\t" /* W1 */                                                         \
+        "v_cmp_lt_f32_e64 s[54:55], v52, %[best]\n\t" /* W2 */                                                         \
+        "v_cmp_lt_f32_e64 s[56:57], v51, v52\n\t" /* LT: child 1 first */                                              \
+        "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t" /* both */                                                        \
+        "s_and_b64 s[60:61], s[58:59], s[56:57]\n\t" /* both, child 1 first */                                         \
+        "s_andn2_b64 s[62:63], s[58:59], s[56:57]\n\t" /* both, child 2 first */                                       \
+        "s_bcnt1_i32_b64 s72, s[60:61]\n\t"                                                                            \
+        "s_bcnt1_i32_b64 s73, s[62:63]\n\t"                                                                            \
+        "s_cmp_gt_u32 s72, s73\n\t" /* scc: the wave takes child 1 first */                                            \
+        "s_cselect_b64 s[64:65], s[52:53], s[54:55]\n\t" /* lanes of the first child */                                \
+        "s_cselect_b64 s[66:67], s[54:55], s[52:53]\n\t" /* lanes of the second child */                               \
+        "s_cselect_b32 s68, s48, s49\n\t" /* first child */                                                            \
+        "s_cselect_b32 s69, s49, s48\n\t" /* second child */                                                           \
+        "s_cselect_b64 s[62:63], s[62:63], s[60:61]\n\t" /* dissenters */                                              \
+        "s_cselect_b64 vcc, -1, 0\n\t"                                                                                 \
+        "v_cndmask_b32_e32 v53, v52, v51, vcc\n\t" /* distances to the first ... */                                    \
+        "v_cndmask_b32_e32 v54, v51, v52, vcc\n\t" /* ... and to the second child */                                   \
+        "s_andn2_b64 s[64:65], s[64:65], s[62:63]\n\t"                                                                 \
+        "s_cbranch_scc0 Lswap%=\n\t"                                                                                   \
+        "s_cmp_gt_u32 s71, %[room]\n\t"                                                                                \
+        "s_cbranch_scc1 Lgiveup%=\n\t"                                                                                 \
+        "s_cmp_eq_u64 s[62:63], 0\n\t"                                                                                 \
+        "s_cbranch_scc1 Lnodis%=\n\t"                                                                                  \
+        "s_mov_b32 m0, s71\n\t" /* the dissenters come back for the first child after the second */                    \
+        "s_nop 0\n\t"                                                                                                  \
+        "v_writelane_b32 v57, s68, m0\n\t"                                                                             \
+        "v_writelane_b32 v58, s62, m0\n\t"                                                                             \
+        "v_writelane_b32 v59, s63, m0\n\t"                                                                             \
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                      \
+        "ds_write_b32 v55, v53\n\t"                                                                                    \
+        "s_add_i32 s71, s71, 1\n"                                                                                      \
+        "Lnodis%=:\n\t"                                                                                                \
+        "s_cmp_eq_u64 s[66:67], 0\n\t"                                                                                 \
+        "s_cbranch_scc1 Lgo%=\n\t"                                                                                     \
+        "s_mov_b32 m0, s71\n\t"                                                                                        \
+        "s_nop 0\n\t"                                                                                                  \
+        "v_writelane_b32 v57, s69, m0\n\t"                                                                             \
+        "v_writelane_b32 v58, s66, m0\n\t"                                                                             \
+        "v_writelane_b32 v59, s67, m0\n\t"                                                                             \
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                      \
+        "ds_write_b32 v55, v54\n\t"                                                                                    \
+        "s_add_i32 s71, s71, 1\n"                                                                                      \
+        "Lgo%=:\n\t"                                                                                                   \
+        "s_mov_b32 s70, s68\n\t"                                                                                       \
+        "s_mov_b64 exec, s[64:65]\n\t"                                                                                 \
+        "s_branch Lnode%=\n"                                                                                           \
+        "Lswap%=:\n\t" /* nobody enters the first child (then nobody dissents): on to the second */                    \
+        "s_cmp_eq_u64 s[66:67], 0\n\t"                                                                                 \
+        "s_cbranch_scc1 Lpop%=\n\t"                                                                                    \
+        "s_mov_b32 s70, s69\n\t"                                                                                       \
+        "s_mov_b64 exec, s[66:67]\n\t"                                                                                 \
+        "s_branch Lnode%=\n"                                                                                           \
+        /* ---- leaf: triangle records (a flags)(e1 id)(e2 -), the last one of the leaf has flag bit 0 */              \
+        "Lleaf%=:\n\t"                                                                                                 \
+        "s_cmp_eq_u32 s70, 0x80000001\n\t"                                                                             \
+        "s_cbranch_scc1 Lpop%=\n\t"                                                                                    \
+        "s_not_b32 s72, s70\n\t"                                                                                       \
+        "s_lshl_b32 s72, s72, 6\n"                                                                                     \
+        "Ltri%=:\n\t"                                                                                                  \
+        "s_load_dwordx8 s[36:43], %[tris], s72\n\t"                                                                    \
+        "s_add_u32 s73, s72, 32\n\t"                                                                                   \
+        "s_load_dwordx4 s[44:47], %[tris], s73\n\t"                                                                    \
+        "s_add_u32 s72, s72, 64\n\t"                                                                                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+        "v_mul_f32_e32 v40, s46, %[dy]\n\t"                                                                            \
+        "v_mul_f32_e32 v41, s45, %[dz]\n\t"                                                                            \
+        "v_mul_f32_e32 v42, s44, %[dz]\n\t"                                                                            \
+        "v_mul_f32_e32 v43, s46, %[dx]\n\t"                                                                            \
+        "v_mul_f32_e32 v44, s45, %[dx]\n\t"                                                                            \
+        "v_mul_f32_e32 v45, s44, %[dy]\n\t"                                                                            \
+        "v_sub_f32_e32 v40, v40, v41\n\t" /* p = cross(d, e2) */                                                       \
+        "v_sub_f32_e32 v41, v42, v43\n\t"                                                                              \
+        "v_sub_f32_e32 v42, v44, v45\n\t"                                                                              \
+        "v_subrev_f32_e32 v43, s36, %[ox]\n\t" /* s = o - a */                                                         \
+        "v_subrev_f32_e32 v44, s37, %[oy]\n\t"                                                                         \
+        "v_subrev_f32_e32 v45, s38, %[oz]\n\t"                                                                         \
+        "v_mul_f32_e32 v46, s40, v40\n\t"                                                                              \
+        "v_mul_f32_e32 v47, s41, v41\n\t"                                                                              \
+        "v_mul_f32_e32 v48, s42, v42\n\t"                                                                              \
+        "v_mul_f32_e32 v40, v43, v40\n\t"                                                                              \
+        "v_mul_f32_e32 v41, v44, v41\n\t"                                                                              \
+        "v_mul_f32_e32 v42, v45, v42\n\t"                                                                              \
+        "v_mul_f32_e32 v49, s42, v44\n\t"                                                                              \
+        "v_mul_f32_e32 v50, s41, v45\n\t"                                                                              \
+        "v_mul_f32_e32 v45, s40, v45\n\t"                                                                              \
+        "v_mul_f32_e32 v51, s42, v43\n\t"                                                                              \
+        "v_mul_f32_e32 v43, s41, v43\n\t"                                                                              \
+        "v_mul_f32_e32 v44, s40, v44\n\t"                                                                              \
+        "v_add_f32_e32 v46, v46, v47\n\t"                                                                              \
+        "v_add_f32_e32 v40, v40, v41\n\t"                                                                              \
+        "v_sub_f32_e32 v41, v49, v50\n\t" /* q = cross(s, e1) */                                                       \
+        "v_sub_f32_e32 v45, v45, v51\n\t"                                                                              \
+        "v_sub_f32_e32 v43, v43, v44\n\t"                                                                              \
+        "v_add_f32_e32 v44, v48, v46\n\t" /* det = dot(e1, p) */                                                       \
+        "v_add_f32_e32 v40, v42, v40\n\t" /* dot(s, p) */                                                              \
+        "v_mul_f32_e32 v42, %[dx], v41\n\t"                                                                            \
+        "v_mul_f32_e32 v46, %[dy], v45\n\t"                                                                            \
+        "v_mul_f32_e32 v41, s44, v41\n\t"                                                                              \
+        "v_mul_f32_e32 v45, s45, v45\n\t"                                                                              \
+        "v_div_scale_f32 v48, s[78:79], v44, v44, 1.0\n\t" /* inv_det = 1 / det, correctly rounded */                  \
+        "v_add_f32_e32 v41, v41, v45\n\t"                                                                              \
+        "v_rcp_f32_e32 v45, v48\n\t"                                                                                   \
+        "v_mul_f32_e32 v47, %[dz], v43\n\t"                                                                            \
+        "v_mul_f32_e32 v43, s46, v43\n\t"                                                                              \
+        "v_add_f32_e32 v41, v43, v41\n\t" /* dot(e2, q) */                                                             \
+        "v_fma_f32 v43, -v48, v45, 1.0\n\t"                                                                            \
+        "v_div_scale_f32 v49, vcc, 1.0, v44, 1.0\n\t"                                                                  \
+        "v_fmac_f32_e32 v45, v43, v45\n\t"                                                                             \
+        "v_mul_f32_e32 v43, v49, v45\n\t"                                                                              \
+        "v_add_f32_e32 v42, v42, v46\n\t"                                                                              \
+        "v_fma_f32 v46, -v48, v43, v49\n\t"                                                                            \
+        "v_fmac_f32_e32 v43, v46, v45\n\t"                                                                             \
+        "v_fma_f32 v46, -v48, v43, v49\n\t"                                                                            \
+        "v_div_fmas_f32 v43, v46, v45, v43\n\t"                                                                        \
+        "v_div_fixup_f32 v43, v43, v44, 1.0\n\t"                                                                       \
+        "v_add_f32_e32 v42, v47, v42\n\t" /* dot(d, q) */                                                              \
+        "v_mul_f32_e32 v40, v40, v43\n\t" /* u */                                                                      \
+        "s_and_b32 s77, s39, 1\n\t"                                                                                    \
+        "v_mul_f32_e32 v42, v42, v43\n\t" /* v */                                                                      \
+        "v_mul_f32_e32 v41, v41, v43\n\t" /* t */                                                                      \
+        "v_cmp_gt_f32_e32 vcc, 0, v40\n\t"                                                                             \
+        "v_cmp_gt_f32_e64 s[80:81], |v40|, s76\n\t"                                                                    \
+        "v_add_f32_e32 v43, -1.0, v40\n\t"                                                                             \
+        "v_mov_b32_e32 v61, s43\n\t"                                                                                   \
+        "v_cmp_lt_f32_e64 s[82:83], |v44|, s76\n\t"                                                                    \
+        "v_cmp_lt_f32_e64 s[84:85], 1.0, v40\n\t"                                                                      \
+        "v_add_f32_e32 v40, v40, v42\n\t"                                                                              \
+        "s_and_b64 s[80:81], vcc, s[80:81]\n\t"                                                                        \
+        "v_cmp_gt_f32_e64 s[86:87], |v43|, s76\n\t"                                                                    \
+        "v_cmp_gt_f32_e64 s[88:89], 0, v42\n\t"                                                                        \
+        "v_cmp_gt_f32_e64 s[52:53], |v42|, s76\n\t"                                                                    \
+        "v_cmp_lt_f32_e32 vcc, 1.0, v40\n\t"                                                                           \
+        "v_add_f32_e32 v40, -1.0, v40\n\t"                                                                             \
+        "s_or_b64 s[82:83], s[82:83], s[80:81]\n\t"                                                                    \
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                   \
+        "s_and_b64 s[88:89], s[88:89], s[52:53]\n\t"                                                                   \
+        "v_cmp_gt_f32_e64 s[80:81], |v40|, s76\n\t"                                                                    \
+        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"                                                                    \
+        "s_and_b64 s[82:83], vcc, s[80:81]\n\t"                                                                        \
+        "s_or_b64 s[84:85], s[88:89], s[84:85]\n\t"                                                                    \
+        "v_cmp_nlt_f32_e64 s[54:55], s76, v41\n\t"                                                                     \
+        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"                                                                    \
+        "s_or_b64 vcc, s[54:55], s[84:85]\n\t"                                                                         \
+        "v_cndmask_b32_e32 v40, v41, v60, vcc\n\t" /* rejected ? inf : t */                                            \
+        "v_cmp_lt_f32_e32 vcc, v40, %[best]\n\t"                                                                       \
+        "s_cmp_eq_u32 s77, 0\n\t"                                                                                      \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_cndmask_b32_e32 %[bid], %[bid], v61, vcc\n\t"                                                               \
+        "v_cndmask_b32_e32 %[best], %[best], v40, vcc\n\t"                                                             \
+        "s_cbranch_scc1 Ltri%=\n"                                                                                      \
+        /* ---- next stack entry that still has a lane whose distance to it is below its closest hit (raytrace.glsl:151) */ \
+        "Lpop%=:\n\t"                                                                                                  \
+        "s_cmp_eq_u32 s71, 0\n\t"                                                                                      \
+        "s_cbranch_scc1 Ldone%=\n\t"                                                                                   \
+        "s_add_i32 s71, s71, -1\n\t"                                                                                   \
+        "s_nop 0\n\t"                                                                                                  \
+        "v_readlane_b32 s78, v58, s71\n\t"                                                                             \
+        "v_readlane_b32 s79, v59, s71\n\t"                                                                             \
+        "s_mov_b64 exec, s[78:79]\n\t"                                                                                 \
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                      \
+        "ds_read_b32 v56, v55\n\t"                                                                                     \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+        "v_cmp_lt_f32_e32 vcc, v56, %[best]\n\t"                                                                       \
+        "s_and_b64 exec, exec, vcc\n\t"                                                                                \
+        "s_cbranch_scc0 Lpop%=\n\t"                                                                                    \
+        "v_readlane_b32 s70, v57, s71\n\t"                                                                             \
+        "s_branch Lnode%=\n"                                                                                           \
+        "Lgiveup%=:\n\t"                                                                                               \
+        "s_mov_b32 %[gave], 1\n"                                                                                       \
+        "Ldone%=:\n\t"                                                                                                 \
         "s_mov_b64 exec, s[74:75]"
-        : [gave] "=&s"(gave), [best] "+v"(best), [bid] "+v"(best_id)
-        : [nodes] "s"(nodes), [tris] "s"(tris), [root] "s"(root), [in0] "s"(in0), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
-          [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [lrow] "v"(lrow),
-          [room] "n"(PK_STACK - 2)
-        : "memory", "vcc", "scc", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
-          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-          "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88",
-          "s89", "s90", "s91", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v56", "v57", "v58", "v59", "v60", "v61");
-    return gave != 0;
-}
+
+#define PK_DEFINE_TRAVERSE(NAME, SLAB)                                                                                                   \
+    __device__ __forceinline__ bool NAME(unsigned long long nodes, unsigned long long tris, int root, unsigned long long in0, rt_vec3 o, \
+                                         rt_vec3 d, rt_vec3 inv, uint32_t lrow, float& best, int& best_id) {                             \
+        int gave;                                                                                                                        \
+        asm volatile(PK_ASM_HEAD PK_ASM_PAD_V PK_ASM_PAD_S SLAB PK_ASM_TAIL                                                              \
+            : [gave] "=&s"(gave), [best] "+v"(best), [bid] "+v"(best_id)                                                                                                     \
+            : [nodes] "s"(nodes), [tris] "s"(tris), [root] "s"(root), [in0] "s"(in0), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),                                           \
+              [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [lrow] "v"(lrow),                                              \
+              [room] "n"(PK_STACK - 2)                                                                                                                                       \
+            : "memory", "vcc", "scc", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",                         \
+              "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",                           \
+              "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88",                           \
+              "s89", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",                           \
+              "v56", "v57", "v58", "v59", "v60", "v61");                                                                                                                     \
+        return gave != 0;                                                                                                                \
+    }
+PK_DEFINE_TRAVERSE(pk_traverse_any, PK_ASM_SLAB_ANY)
+PK_DEFINE_TRAVERSE(pk_traverse_ppp, PK_ASM_SLAB_EXPAND(PK_XP, PK_YP, PK_ZP))
+PK_DEFINE_TRAVERSE(pk_traverse_npp, PK_ASM_SLAB_EXPAND(PK_XN, PK_YP, PK_ZP))
+PK_DEFINE_TRAVERSE(pk_traverse_pnp, PK_ASM_SLAB_EXPAND(PK_XP, PK_YN, PK_ZP))
+PK_DEFINE_TRAVERSE(pk_traverse_nnp, PK_ASM_SLAB_EXPAND(PK_XN, PK_YN, PK_ZP))
+PK_DEFINE_TRAVERSE(pk_traverse_ppn, PK_ASM_SLAB_EXPAND(PK_XP, PK_YP, PK_ZN))
+PK_DEFINE_TRAVERSE(pk_traverse_npn, PK_ASM_SLAB_EXPAND(PK_XN, PK_YP, PK_ZN))
+PK_DEFINE_TRAVERSE(pk_traverse_pnn, PK_ASM_SLAB_EXPAND(PK_XP, PK_YN, PK_ZN))
+PK_DEFINE_TRAVERSE(pk_traverse_nnn, PK_ASM_SLAB_EXPAND(PK_XN, PK_YN, PK_ZN))
 
 template <bool COUNT>
 __global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene sc, DCamera cam, PathsArgs a) {
     __shared__ float s_dist[PK_BLOCK / 64][PK_STACK][64];
-    __shared__ uint32_t s_next;
     const int tid = threadIdx.x, lane = tid & 63;
     float(*const dist_rows)[64] = s_dist[tid >> 6];
-    if (tid == 0) s_next = 0;
-    __syncthreads();
     const pk_cf4 nodes = (pk_cf4)(uintptr_t)sc.nodes;
     const pk_cf4 tris = (pk_cf4)(uintptr_t)sc.tris;
-    // same dealing of items to workgroups as in k_paths: every round of gridDim.x items is split into 8 runs, one per XCD
-    const uint32_t xcd_slot = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
     Counters tot = {0, 0, 0, 0, 0};
     unsigned long long tot_paths = 0;
 
-    // Persistent waves: launching one short-lived workgroup per four items instead (so that the hardware balances tiles of
-    // sky against tiles on the object) measured 2 % (dragon80k) to 8 % (teapot) slower end to end.
+    // Persistent waves that pull their work: a wave takes `pk_chunk` consecutive items at a time from a counter in memory
+    // (one per XCD, workgroup b runs on XCD b mod 8; XCD x owns the chunks x, x + 8, ... so that the waves sharing an L2 work
+    // on neighbouring tiles).  The workgroups of a launch are not always resident together -- next to a path kernel only half
+    // of them fit -- and with a fixed share of the items per workgroup the late ones would start a second round with the chip
+    // half empty.  (One short-lived workgroup per four items, so that the hardware does the balancing, measured 2 % (dragon80k)
+    // to 8 % (teapot) slower end to end.)  The counters are zeroed on the stream ahead of the launch.
+    const uint32_t nx = (gridDim.x & 7u) == 0u ? 8u : 1u, xcd = nx == 8u ? (blockIdx.x & 7u) : 0u;
+    uint32_t* const ctr = a.pk_ctr + xcd * 16u;
+    uint32_t item = 0, left = 0;
     for (;;) {
-        uint32_t k = 0;
-        if (lane == 0) k = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-        const uint32_t item = xcd_slot + k * gridDim.x;
-        if (item >= a.total_tiles) break;
+        if (left == 0u) {
+            uint32_t g = 0;
+            if (lane == 0) g = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            item = (g * nx + xcd) * a.pk_chunk;
+            left = a.pk_chunk;
+        } else {
+            item++;
+        }
+        left--;
+        if (item >= a.total_tiles) break;   // the chunks after this one lie further out still
         uint32_t f;
         int gx, gy;
         item_pixel(a, item, lane, f, gx, gy);
@@ -358,8 +445,30 @@ __global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene s
 
         if (!COUNT) {   // the hand-written loop; the counting build keeps the C++ one below
             const uint32_t lrow = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)&dist_rows[0][lane];
-            gave_up = pk_traverse((unsigned long long)(uintptr_t)a.rnodes, (unsigned long long)(uintptr_t)sc.tris, sc.root_ref,
-                                  __builtin_amdgcn_ballot_w64(in), o, d, inv, lrow, best, best_id);
+            const unsigned long long in0 = __builtin_amdgcn_ballot_w64(in);
+            // the form of the slab tests: one of the eight sign-specific ones when every ray of the packet points the same
+            // way along each axis with a finite reciprocal (all tiles but the ones on the image's two centre lines)
+            int form = 8;
+            if (a.finite_boxes) {
+                const unsigned long long px = __builtin_amdgcn_ballot_w64(inv.x > 0.0f && inv.x < RT_INF), nx = __builtin_amdgcn_ballot_w64(inv.x < 0.0f && inv.x > -RT_INF);
+                const unsigned long long py = __builtin_amdgcn_ballot_w64(inv.y > 0.0f && inv.y < RT_INF), ny = __builtin_amdgcn_ballot_w64(inv.y < 0.0f && inv.y > -RT_INF);
+                const unsigned long long pz = __builtin_amdgcn_ballot_w64(inv.z > 0.0f && inv.z < RT_INF), nz = __builtin_amdgcn_ballot_w64(inv.z < 0.0f && inv.z > -RT_INF);
+                const bool ux = (px & in0) == in0 || (nx & in0) == in0, uy = (py & in0) == in0 || (ny & in0) == in0, uz = (pz & in0) == in0 || (nz & in0) == in0;
+                if (ux && uy && uz) form = ((nx & in0) == in0 ? 1 : 0) | ((ny & in0) == in0 ? 2 : 0) | ((nz & in0) == in0 ? 4 : 0);
+            }
+#define PK_GO(F_) gave_up = F_((unsigned long long)(uintptr_t)a.rnodes, (unsigned long long)(uintptr_t)sc.tris, sc.root_ref, in0, o, d, inv, lrow, best, best_id)
+            switch (form) {
+                case 0: PK_GO(pk_traverse_ppp); break;
+                case 1: PK_GO(pk_traverse_npp); break;
+                case 2: PK_GO(pk_traverse_pnp); break;
+                case 3: PK_GO(pk_traverse_nnp); break;
+                case 4: PK_GO(pk_traverse_ppn); break;
+                case 5: PK_GO(pk_traverse_npn); break;
+                case 6: PK_GO(pk_traverse_pnn); break;
+                case 7: PK_GO(pk_traverse_nnn); break;
+                default: PK_GO(pk_traverse_any); break;
+            }
+#undef PK_GO
             cur = RT_REF_IDLE;
         }
 #ifdef PK_DEBUG
