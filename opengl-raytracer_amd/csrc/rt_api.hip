@@ -203,6 +203,7 @@ struct rt_context {
     int tune_stagger = 1;                      // 1: the primary pass of a pipelined launch waits for the previous launch's (launch_paths_batch)
     int tune_queue_blocks = 1;                 // workgroups per CU of a pipelined path launch that starts from k_primary's hit queues
     int tune_last_blocks = PT_BLOCKS_PER_CU;   // ... of the last such launch of a call (no primary pass runs next to it)
+    int tune_split = 0;                        // frames of a call over its launches: 0 full launches then the remainder, 1 evenly, 2 remainder first
     int tune_primary_chunk = 4;                // items a wave of k_primary takes per grab
     int tune_primary_blocks = PK_BLOCKS_PER_CU;  // workgroups per CU of k_primary's grid
     int tune_signed_slabs = 1;                 // k_primary: sign-specific slab tests where a packet's rays allow them (0: A/B runs)
@@ -1016,6 +1017,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_OVERLAP")) c->tune_overlap = atoi(e);
     if (const char* e = getenv("RT_TUNE_STAGGER")) c->tune_stagger = atoi(e);
     if (const char* e = getenv("RT_TUNE_QUEUE_BLOCKS")) c->tune_queue_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_SPLIT")) c->tune_split = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_CHUNK")) c->tune_primary_chunk = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_BLOCKS")) c->tune_primary_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_SIGNED_SLABS")) c->tune_signed_slabs = atoi(e);
@@ -1807,8 +1809,11 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
     HIPCHK(c, hipSetDevice(c->device));
     DCamera dc = make_dcamera(cam, p->width, p->height);
     const uint32_t batch = paths_batch((size_t)p->width * p->height) / p->rays_per_pixel;  // frames x samples staged per launch
-    for (uint32_t f = 0; f < p->frames; f += batch) {
-        uint32_t n = p->frames - f < batch ? p->frames - f : batch;
+    const uint32_t launches = (p->frames + batch - 1) / batch;
+    const uint32_t even = c->tune_split == 1 ? (p->frames + launches - 1) / launches : batch;
+    for (uint32_t f = 0, n = 0; f < p->frames; f += n) {
+        n = p->frames - f < even ? p->frames - f : even;
+        if (c->tune_split == 2 && f == 0 && p->frames > batch && p->frames % batch) n = p->frames % batch;   // remainder first
         // "followed": another launch of this call comes after this one, or this one is a short remainder that starts while
         // its predecessor still drains (workgroups that start late carry a full share of the items: bench.py --steps 20,
         // 16 + 4 frames: 4.70 ms with one workgroup per CU for the remainder, 4.75 with two; 16, 64 steps: 4.43 -> 4.01,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of render-library builds with bench.py: the product library and every library under csrc/diag/, at the driver's 20 steps
 # and at 128, two rounds.  usage (GPU box, repo root): ab_bench.sh [bench.py args]
-for round in 1 2; do for ST in 20 128; do
+for round in 1 2; do for ST in ${AB_STEPS:-20 128}; do
 for L in $PWD/opengl-raytracer_amd/csrc/librt_hip.so $PWD/opengl-raytracer_amd/csrc/diag/*.so; do
   [ -f "$L" ] || continue
   printf "%-5s %-16s " $ST "$(basename $L)"
