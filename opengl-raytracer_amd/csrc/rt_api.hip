@@ -152,7 +152,7 @@ struct rt_context {
     size_t num_recs = 0;          // inner-node records of the current scene
     float4* d_hitq = nullptr;
     uint32_t* d_hcount = nullptr;
-    uint32_t* d_pkctr = nullptr;               // k_primary's chunk counters: 8 x 16 words per staging slot
+    uint32_t* d_pkctr = nullptr;               // k_primary's chunk counters: PK_COUNTERS x 16 words per staging slot
     size_t hitq_items = 0;        // (tile, frame) items the two buffers hold, all slots together
     uint2* d_pspill = nullptr;    // stack spill area, one copy per pipeline slot
     size_t pspill_entries = 0;
@@ -203,8 +203,9 @@ struct rt_context {
     int tune_stagger = 1;                      // 1: the primary pass of a pipelined launch waits for the previous launch's (launch_paths_batch)
     int tune_queue_blocks = 1;                 // workgroups per CU of a pipelined path launch that starts from k_primary's hit queues
     int tune_last_blocks = PT_BLOCKS_PER_CU;   // ... of the last such launch of a call (no primary pass runs next to it)
+    int tune_ahead_t4 = 6, tune_ahead_t8 = 40; // steady calls after which a frame loop is traced ahead 4 / tune_ahead frames at a time
     int tune_split = 0;                        // frames of a call over its launches: 0 full launches then the remainder, 1 evenly, 2 remainder first
-    int tune_primary_chunk = 4;                // items a wave of k_primary takes per grab
+    int tune_primary_chunk = 0;                // items a wave of k_primary takes per grab (0: by the launch's number of frames)
     int tune_primary_blocks = PK_BLOCKS_PER_CU;  // workgroups per CU of k_primary's grid
     int tune_signed_slabs = 1;                 // k_primary: sign-specific slab tests where a packet's rays allow them (0: A/B runs)
     int tune_packets = 1;                      // primary rays traced tile by tile: 1 by rule (use_packets), 0 never, 2 always (A/B runs)
@@ -700,10 +701,14 @@ static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& 
     const size_t share = c->hitq_items / RT_LANES;
     a.hitq = c->d_hitq + (size_t)slot * share * 64;
     a.hcount = c->d_hcount + (size_t)slot * share;
-    a.pk_ctr = c->d_pkctr + (size_t)slot * 128;
-    a.pk_chunk = (uint32_t)c->tune_primary_chunk;
-    (void)hipMemsetAsync(a.pk_ctr, 0, 128 * sizeof(uint32_t), st);
     dim3 grid(c->num_cus * c->tune_primary_blocks), blk(PK_BLOCK);
+    a.pk_ctr = c->d_pkctr + (size_t)slot * (PK_COUNTERS * 16);
+    // consecutive items are the frames of one tile (identical packets: the second one finds its records in the scalar cache),
+    // so long chunks pay for launches of many frames; short launches need small ones for balance (dragon80k: 16-frame launches
+    // 13.6 / 14.2 / 14.4 Grays/s with chunks of 2 / 3 / 4, single-frame launches 0.30 / 0.31 / 0.34 ms per frame with 1 / 2 / 4)
+    a.pk_chunk = c->tune_primary_chunk > 0 ? (uint32_t)c->tune_primary_chunk : a.num_frames >= 16u ? 4u : a.num_frames >= 8u ? 2u : 1u;
+    // every counter starts behind the chunks its waves take without asking
+    (void)hipMemsetD32Async((hipDeviceptr_t)a.pk_ctr, (int)(grid.x / pk_counters(grid.x) * (PK_BLOCK / 64)), PK_COUNTERS * 16, st);
     if (count)
         hipLaunchKernelGGL((k_primary<true>), grid, blk, 0, st, c->sc, dc, a);
     else
@@ -894,7 +899,7 @@ static int frame_call(rt_context* c, const DCamera& dc, const rt_params* p, uint
     if (ah.valid && !(frame_count >= ah.base && frame_count < ah.base + ah.count)) ahead_discard(c);
     // Batch size by how long the loop has been steady: what is traced ahead and never asked for is wasted, and a loop that
     // has run for 40 frames is likelier to run for 8 more than one that has run for 3.
-    const uint32_t want = ah.streak < 2u ? 1u : ah.streak < 6u ? 2u : ah.streak < 40u ? 4u : (uint32_t)c->tune_ahead;
+    const uint32_t want = ah.streak < 2u ? 1u : ah.streak < (uint32_t)c->tune_ahead_t4 ? 2u : ah.streak < (uint32_t)c->tune_ahead_t8 ? 4u : (uint32_t)c->tune_ahead;
     const uint32_t cap = std::min<uint32_t>(paths_batch(pixels), std::min<uint32_t>(want, (uint32_t)c->tune_ahead));
     if (!ah.valid) {
         const uint32_t k = cap;
@@ -994,7 +999,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
             return rc;
         }
     }
-    if ((e = hipMalloc(&c->d_pkctr, (size_t)RT_LANES * 128 * sizeof(uint32_t))) != hipSuccess) {
+    if ((e = hipMalloc(&c->d_pkctr, (size_t)RT_LANES * PK_COUNTERS * 16 * sizeof(uint32_t))) != hipSuccess) {
         int rc = fail(nullptr, RT_EDEVICE, "context set-up failed: %s", hipGetErrorString(e));
         rt_destroy(c);
         return rc;
@@ -1017,6 +1022,8 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_OVERLAP")) c->tune_overlap = atoi(e);
     if (const char* e = getenv("RT_TUNE_STAGGER")) c->tune_stagger = atoi(e);
     if (const char* e = getenv("RT_TUNE_QUEUE_BLOCKS")) c->tune_queue_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_AHEAD_T4")) c->tune_ahead_t4 = atoi(e);
+    if (const char* e = getenv("RT_TUNE_AHEAD_T8")) c->tune_ahead_t8 = atoi(e);
     if (const char* e = getenv("RT_TUNE_SPLIT")) c->tune_split = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_CHUNK")) c->tune_primary_chunk = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_BLOCKS")) c->tune_primary_blocks = atoi(e);
@@ -1038,7 +1045,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->tune_queue_blocks = clamp(c->tune_queue_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_last_blocks = clamp(c->tune_last_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_primary_blocks = clamp(c->tune_primary_blocks, 1, PK_BLOCKS_PER_CU);
-    c->tune_primary_chunk = clamp(c->tune_primary_chunk, 1, 64);
+    c->tune_primary_chunk = clamp(c->tune_primary_chunk, 0, 64);
     c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
 #endif
     hipDeviceProp_t prop;

@@ -31,6 +31,10 @@
 #define PK_STACK 19                  // packet-stack entries (a 256-byte row of per-lane distances each, in LDS)
 #endif
 #define PK_TRACE_ITEM 0xffffffffu
+#define PK_COUNTERS 64u              // item counters of a k_primary launch, 16 words apart
+
+// How many of them a grid of this size uses, and with how many waves each starts (see k_primary).
+__host__ __device__ inline uint32_t pk_counters(uint32_t grid) { return grid % PK_COUNTERS == 0u ? PK_COUNTERS : grid % 8u == 0u ? 8u : 1u; }
 
 typedef float pk_f4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) pk_f4* pk_cf4;   // constant address space: uniform addresses load through the scalar cache
@@ -394,22 +398,25 @@ __global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene s
     Counters tot = {0, 0, 0, 0, 0};
     unsigned long long tot_paths = 0;
 
-    // Persistent waves that pull their work: a wave takes `pk_chunk` consecutive items at a time from a counter in memory
-    // (one per XCD, workgroup b runs on XCD b mod 8; XCD x owns the chunks x, x + 8, ... so that the waves sharing an L2 work
-    // on neighbouring tiles).  The workgroups of a launch are not always resident together -- next to a path kernel only half
-    // of them fit -- and with a fixed share of the items per workgroup the late ones would start a second round with the chip
-    // half empty.  (One short-lived workgroup per four items, so that the hardware does the balancing, measured 2 % (dragon80k)
-    // to 8 % (teapot) slower end to end.)  The counters are zeroed on the stream ahead of the launch.
-    const uint32_t nx = (gridDim.x & 7u) == 0u ? 8u : 1u, xcd = nx == 8u ? (blockIdx.x & 7u) : 0u;
-    uint32_t* const ctr = a.pk_ctr + xcd * 16u;
-    uint32_t item = 0, left = 0;
+    // Persistent waves that pull their work: a wave takes `pk_chunk` consecutive items at a time.  Chunk c belongs to
+    // counter c mod PK_COUNTERS; workgroup b uses counter b mod PK_COUNTERS, so the waves sharing an L2 (workgroup b runs
+    // on XCD b mod 8) work on neighbouring tiles.  A wave's first chunk is the one with its own rank among the waves of its
+    // counter -- no atomic, no queue of 8,192 waves in front of a handful of addresses at the start of the launch -- and
+    // the counters start at that number of waves (set on the stream ahead of the launch); an agent-scope atomic in memory
+    // hands out the rest.  The workgroups of a launch are not always resident together -- next to a path kernel only half
+    // of them fit -- and with a fixed share of the items per workgroup the late ones would start a second round with the
+    // chip half empty (one short-lived workgroup per four items, so that the hardware does the balancing, measured 2 %
+    // (dragon80k) to 8 % (teapot) slower end to end).
+    const uint32_t nctr = pk_counters(gridDim.x), cid = blockIdx.x % nctr;
+    uint32_t* const ctr = a.pk_ctr + cid * 16u;
+    uint32_t item = ((blockIdx.x / nctr * (PK_BLOCK / 64u) + (uint32_t)(tid >> 6)) * nctr + cid) * a.pk_chunk - 1u, left = a.pk_chunk + 1u;
     for (;;) {
-        if (left == 0u) {
+        if (left == 1u) {
             uint32_t g = 0;
             if (lane == 0) g = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-            item = (g * nx + xcd) * a.pk_chunk;
-            left = a.pk_chunk;
+            item = (g * nctr + cid) * a.pk_chunk;
+            left = a.pk_chunk + 1u;
         } else {
             item++;
         }
