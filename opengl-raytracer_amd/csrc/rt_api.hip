@@ -206,6 +206,7 @@ struct rt_context {
     int tune_ahead_t4 = 6, tune_ahead_t8 = 40; // steady calls after which a frame loop is traced ahead 4 / tune_ahead frames at a time
     int tune_split = 0;                        // frames of a call over its launches: 0 full launches then the remainder, 1 evenly, 2 remainder first
     int tune_primary_chunk = 0;                // items a wave of k_primary takes per grab (0: by the launch's number of frames)
+    int tune_primary_grid = 0;                 // > 0: k_primary's grid as is (tests of the counter arrangements for grids that are no multiple of 64 or 8)
     int tune_primary_blocks = PK_BLOCKS_PER_CU;  // workgroups per CU of k_primary's grid
     int tune_signed_slabs = 1;                 // k_primary: sign-specific slab tests where a packet's rays allow them (0: A/B runs)
     int tune_packets = 1;                      // primary rays traced tile by tile: 1 by rule (use_packets), 0 never, 2 always (A/B runs)
@@ -701,7 +702,7 @@ static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& 
     const size_t share = c->hitq_items / RT_LANES;
     a.hitq = c->d_hitq + (size_t)slot * share * 64;
     a.hcount = c->d_hcount + (size_t)slot * share;
-    dim3 grid(c->num_cus * c->tune_primary_blocks), blk(PK_BLOCK);
+    dim3 grid(c->tune_primary_grid > 0 ? c->tune_primary_grid : c->num_cus * c->tune_primary_blocks), blk(PK_BLOCK);
     a.pk_ctr = c->d_pkctr + (size_t)slot * (PK_COUNTERS * 16);
     // consecutive items are the frames of one tile (identical packets: the second one finds its records in the scalar cache),
     // so long chunks pay for launches of many frames; short launches need small ones for balance (dragon80k: 16-frame launches
@@ -1026,6 +1027,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_AHEAD_T8")) c->tune_ahead_t8 = atoi(e);
     if (const char* e = getenv("RT_TUNE_SPLIT")) c->tune_split = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_CHUNK")) c->tune_primary_chunk = atoi(e);
+    if (const char* e = getenv("RT_TUNE_PRIMARY_GRID")) c->tune_primary_grid = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_BLOCKS")) c->tune_primary_blocks = atoi(e);
     if (const char* e = getenv("RT_TUNE_SIGNED_SLABS")) c->tune_signed_slabs = atoi(e);
     if (const char* e = getenv("RT_TUNE_LAST_BLOCKS")) c->tune_last_blocks = atoi(e);
@@ -1046,6 +1048,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->tune_last_blocks = clamp(c->tune_last_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_primary_blocks = clamp(c->tune_primary_blocks, 1, PK_BLOCKS_PER_CU);
     c->tune_primary_chunk = clamp(c->tune_primary_chunk, 0, 64);
+    c->tune_primary_grid = clamp(c->tune_primary_grid, 0, 1 << 14);
     c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
 #endif
     hipDeviceProp_t prop;

@@ -841,3 +841,39 @@ def test_packet_that_outgrows_its_stack_hands_the_tile_back(pkg, oracle, gpu_ctx
         params = pkg.make_params(200, 120, frames=3, flags=extra)
         want, cnt_o = oracle.render(scene, cam, params)
         render_both_ways(pkg, gpu_ctx, cam, params, want, cnt_o, what=f"chain {extra}")
+
+
+@pytest.mark.parametrize("env", [
+    {"RT_TUNE_PRIMARY_GRID": "1000"},                                # a multiple of 8 but not of 64: eight counters
+    {"RT_TUNE_PRIMARY_GRID": "999", "RT_TUNE_PRIMARY_CHUNK": "3"},   # neither: one counter
+    {"RT_TUNE_PRIMARY_GRID": "7"},                                   # fewer waves than a frame has tiles
+    {"RT_TUNE_PRIMARY_CHUNK": "1"},
+    {"RT_TUNE_PRIMARY_CHUNK": "64"},                                 # longer than a short launch has items per wave
+    {"RT_TUNE_SIGNED_SLABS": "0"},                                   # every packet through the general slab tests
+    {"RT_TUNE_LAST_BLOCKS": "1", "RT_TUNE_QUEUE_BLOCKS": "2"},
+])
+def test_packet_kernel_work_distribution_variants(pkg, oracle, scenes, env):
+    """k_primary's waves pull chunks of work items from counters in memory; how many counters, how long the chunks and how
+    large the grid is must not show in the image (every item traced exactly once).  Forced through the tuning build; also
+    the general form of the slab tests where the default picks the sign-specific ones, and the other workgroup counts of the
+    path kernel behind it."""
+    import os
+    os.environ.update(env)
+    try:
+        ctx = pkg.RenderContext(0, tunable=True)
+    finally:
+        for k in env:
+            del os.environ[k]
+    for name, frames in (("dragon80k", 18), ("teapot", 3)):
+        scene = scenes(name)
+        ctx.upload_scene(scene)
+        cam = pkg.make_camera(yaw=0.3, **CAMERAS[name])
+        p = pkg.make_params(333, 217, frames=frames, flags=pkg.RT_FLAG_PACKETS)
+        want, _ = oracle.render(scene, cam, p)
+        got = ctx.render(cam, p)
+        assert np.array_equal(bits(got), bits(want)), f"{name} {env}: {int((bits(got) != bits(want)).any(axis=-1).sum())} pixels differ"
+        p1 = pkg.make_params(333, 217, frames=1, frame_base=frames, flags=pkg.RT_FLAG_PACKETS)
+        want1, _ = oracle.render(scene, cam, p1, want.copy())
+        got1 = ctx.render(cam, p1, got.copy())
+        assert np.array_equal(bits(got1), bits(want1))
+    ctx.close()
