@@ -93,7 +93,7 @@ struct CullPad {
 
 struct rt_context {
     int device = 0;
-    bool finite_boxes = false;   // every box of the current tree has finite corners (known from the upload's checks / the builder's reductions)
+    bool finite_boxes = false;   // every box of the current tree has finite corners with min <= max (known from the upload's checks; the builder's boxes are unions of at least one triangle each)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -1227,9 +1227,11 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     // vertex, is traversed uncut.
     double edge_prod_max = 0.0, edge_max = 0.0;
     bool nested = true;
+    bool ordered = true;   // every box has min <= max along every axis (an empty leaf may come with any box)
     for (int i = 0; i < V; i++) {
         const Visit& v = order[i];
         const float* box = s->nodes + (size_t)12 * v.node;
+        for (int j = 0; j < 3; j++) ordered = ordered && box[j] <= box[4 + j];
         if (v.parent >= 0) {
             const float* pb = s->nodes + (size_t)12 * order[v.parent].node;
             for (int j = 0; j < 3; j++) nested = nested && box[j] >= pb[j] && box[4 + j] <= pb[4 + j];
@@ -1325,7 +1327,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
         double diag2 = 0.0;
         for (int k = 0; k < 3; k++) diag2 += ((double)s->nodes[4 + k] - s->nodes[k]) * ((double)s->nodes[4 + k] - s->nodes[k]);
         c->cull = nested ? cull_pad_of(std::sqrt(diag2), edge_prod_max, edge_max, c->tune_cull_reach) : CullPad();
-        c->finite_boxes = nested && std::isfinite(diag2);   // nested: every box inside its parent's, comparisons false on a NaN
+        c->finite_boxes = nested && ordered && std::isfinite(diag2);   // nested: every box inside its parent's; comparisons are false on a NaN
     }
     c->has_scene = true;
     // a deeper tree may need a larger spill area: force re-allocation on the next render

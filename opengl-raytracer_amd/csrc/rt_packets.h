@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
         "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t" /* d2 */
 
 // The slab tests for a packet whose rays all point the same way along every axis (and have finite reciprocals), on a tree
-// whose boxes are finite: with 1/d > 0 the product with the box's lower corner is the smaller of the two (rounding is
+// whose boxes are finite and not inverted (min <= max): with 1/d > 0 the product with the box's lower corner is the smaller of the two (rounding is
 // monotonic, and lo - o <= hi - o), with 1/d < 0 the one with the upper corner, so the min and max of raytrace.glsl:117-118
 // are known in advance and 12 of the 38 vector instructions go away.  Same values, hence same distances, as the general
 // form (a zero may differ in sign where both products are zeros; the distance handed on is then the literal 0 either way).

@@ -503,12 +503,13 @@ def _tiny_scene(pkg, tris, nodes=None):
     return pkg.Scene(nodes, pad(tris[:, 0]), pad(tris[:, 1]), pad(tris[:, 2]), pkg.make_colours(5, T))
 
 
-@pytest.mark.parametrize("case", ["root_is_leaf", "empty_leaf", "degenerate_triangle", "nan_column"])
+@pytest.mark.parametrize("case", ["root_is_leaf", "empty_leaf", "empty_leaf_inverted_box", "degenerate_triangle", "nan_column"])
 @pytest.mark.parametrize("pipeline", ["paths", "wavefront", "megakernel"])
 def test_edge_scenes(pkg, oracle, gpu_ctx, case, pipeline):
-    """Ragged inputs: a tree that is a single leaf, a leaf with an empty triangle range (b < a), a degenerate
-    triangle (NaN normal, normals.glsl:18), and boxes ending exactly on the plane x = camera.x (0 * inf = NaN in
-    the slab test of the centre pixel column)."""
+    """Ragged inputs: a tree that is a single leaf, a leaf with an empty triangle range (b < a) -- also with its box given
+    upside down (max < min), which the slab test of raytrace.glsl:113-125 reads like the box the right way up --, a
+    degenerate triangle (NaN normal, normals.glsl:18), and boxes ending exactly on the plane x = camera.x (0 * inf = NaN
+    in the slab test of the centre pixel column)."""
     big = [[-3, -2, 5], [3, -2, 5], [0, 3, 6]]
     if case == "root_is_leaf":
         scene = _tiny_scene(pkg, [big])
@@ -522,6 +523,8 @@ def test_edge_scenes(pkg, oracle, gpu_ctx, case, pipeline):
                           [*lo, 0, *hi, 0, 1.0, 0.0, 0.0, 0],      # leaf with triangle 0
                           [*lo, 0, *hi, 0, 1.0, 1.0, 0.0, 0]],     # leaf with the empty range [1, 0]
                          dtype=np.float32)
+        if case == "empty_leaf_inverted_box":
+            nodes[2, 0:3], nodes[2, 4:7] = hi, lo
         scene = _tiny_scene(pkg, [big], nodes)
     cam = pkg.make_camera(pos=(0.0, 0.0, -2.0))
     p = pkg.make_params(128, 96, frames=2, flags=_pipeline_flags(pkg, pipeline))
