@@ -74,8 +74,8 @@ extern "C" {
                                      the default pipeline decides per launch: where triangles are large against a pixel's
                                      footprint (estimated from the root box, the triangle count and the camera) the 64 primary
                                      rays of every 8x8-pixel tile walk the BVH together, one node fetch per wave, each ray in
-                                     the reference's own visit order (raytrace.glsl:127-195); elsewhere, and with
-                                     RT_FLAG_FIX_INVDIR, every lane follows its own ray.  Same pixels and counters either way;
+                                     the reference's own visit order (raytrace.glsl:127-195); elsewhere every lane follows
+                                     its own ray.  Same pixels and counters either way;
                                      the flag exists so that tests and measurements can pin the choice.  Ignored with
                                      RT_FLAG_NO_CULL (the literal lane-by-lane traversal), RT_FLAG_REUSE_PRIMARY and on the
                                      other pipelines.  No counterpart in the reference. */

@@ -477,13 +477,15 @@ static size_t items_per_frame(int width, int height) {
     return tx * (size_t)((height + 7) / 8);
 }
 
-static int ensure_paths_buffers(rt_context* c, int width, int height) {
+// `packets`: the launch traces its primary rays tile by tile and needs the hit queues too (as large again as the staged samples:
+// a context that never does -- a scene of sub-pixel triangles -- never allocates them).
+static int ensure_paths_buffers(rt_context* c, int width, int height, bool packets) {
     const size_t pixels = (size_t)width * height;
     size_t want_spill = c->max_depth > PT_STACK ? (size_t)(c->max_depth - PT_STACK + 1) : 0;
     // sized in bytes: a smaller image may render more frames per launch than the one the buffer was made for
     const uint32_t batch = paths_batch(pixels);
     const size_t want_bytes = (size_t)RT_LANES * batch * pixels * sizeof(float4);  // one slot of `batch` frames per lane
-    const size_t want_items = (size_t)RT_LANES * batch * items_per_frame(width, height);
+    const size_t want_items = packets ? (size_t)RT_LANES * batch * items_per_frame(width, height) : 0;
     if (want_bytes <= c->samples_bytes && want_spill <= c->pspill_entries && want_items <= c->hitq_items) return RT_OK;
     ahead_reset(c);  // launches traced ahead still write the staging area that is about to be freed
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -604,10 +606,11 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
 //     many lanes at once: 40/16 -> 10/6: 0.293 -> 0.268, 0.205 -> 0.189, 1.02 -> 0.93;
 //   primary rays traced lane by lane, stale invDir: 40/16 -> 16/6: 0.301 -> 0.290, 0.231 -> 0.221, 1.078 -> 1.03
 //     (9.27 M-triangle grid 0.99, unchanged);
-//   RT_FLAG_FIX_INVDIR (long paths, most lanes carry bounce rays): 40/16 stays (16/6: 0.508 -> 0.527).
+//   RT_FLAG_FIX_INVDIR (long paths, most lanes carry bounce rays): 40/16 stays (16/6: 0.508 -> 0.527); behind k_primary's hit
+//     queues 24/8 (bench.py --fix-invdir --steps 64: 7.26 -> 7.53 Grays/s).
 static void paths_thresholds(const rt_context* c, bool fix, int pmode, PathsArgs& a) {
-    a.min_trav = fix ? PT_MIN_TRAV : (pmode == PM_QUEUE || pmode == PM_REUSE ? 10 : 16);
-    a.min_service = fix ? PT_MIN_SERVICE : 6;
+    a.min_trav = fix ? (pmode == PM_QUEUE ? 24 : PT_MIN_TRAV) : (pmode == PM_QUEUE || pmode == PM_REUSE ? 10 : 16);
+    a.min_service = fix ? (pmode == PM_QUEUE ? 8 : PT_MIN_SERVICE) : 6;
     if (c->tune_min_trav > 0) a.min_trav = c->tune_min_trav;
     if (c->tune_min_service > 0) a.min_service = c->tune_min_service;
 }
@@ -653,14 +656,13 @@ static void launch_k_paths(const rt_context* c, const DCamera& dc, const PathsAr
 //
 // A packet pays when the 64 rays of a tile visit much the same nodes, i.e. when triangles are large against a tile's
 // footprint.  Estimated from what the host knows without looking at the mesh: triangle size ~ sqrt(surface of the root
-// box / triangles), pixel footprint at the distance of the root box's centre.  Measured (ms per frame, lane by lane ->
-// packets): teapot (65 pixels per triangle) 0.221 -> 0.189, dragon80k 1080p (7 pixels) 0.290 -> 0.268, 3840x2160 (15
-// pixels) 1.03 -> 0.93, 9.27 M-triangle grid (1 pixel: a tile's rays part ways a few levels down) 0.99 -> 1.12.  With
-// RT_FLAG_FIX_INVDIR most of the work is bounce rays and splitting the primary rays off loses (0.51 -> 0.58).
+// box / triangles), pixel footprint at the distance of the root box's centre.  Measured (tools/packets_ab.sh, ms per frame,
+// lane by lane -> packets): teapot (ratio 51) 0.220 -> 0.185, dragon80k 1080p (7.6) 0.291 -> 0.23, 3840x2160 (15) 1.027 ->
+// 0.80-0.83, with RT_FLAG_FIX_INVDIR 0.508 -> 0.491, 9.27 M-triangle grid (ratio 1: a tile's rays part ways a few levels
+// down) 0.977 -> 0.968 -- no gain there, and the hit queues would double the staging memory.
 static bool use_packets(const rt_context* c, const rt_params* p, const DCamera& dc) {
     if (c->tune_packets == 0 || (p->flags & (RT_FLAG_NO_CULL | RT_FLAG_REUSE_PRIMARY)) || p->rays_per_pixel != 1) return false;
     if (c->tune_packets >= 2 || (p->flags & RT_FLAG_PACKETS)) return true;
-    if (p->flags & RT_FLAG_FIX_INVDIR) return false;
     const double ex = (double)c->sc.rmax[0] - c->sc.rmin[0], ey = (double)c->sc.rmax[1] - c->sc.rmin[1], ez = (double)c->sc.rmax[2] - c->sc.rmin[2];
     const double area = 2.0 * (ex * ey + ey * ez + ez * ex);
     double dist2 = 0.0;
@@ -670,7 +672,10 @@ static bool use_packets(const rt_context* c, const rt_params* p, const DCamera& 
     }
     const double tri = std::sqrt(area / (double)(c->num_tris > 0 ? c->num_tris : 1));
     const double pixel = (double)dc.pixel_width / (double)dc.viewport_dist * std::sqrt(dist2);
-    return tri >= 3.0 * pixel;   // NaN (degenerate box or camera): false
+    // calibrated on dragon80k at falling resolutions (tools/packets_threshold.sh; ratio, ms per frame lane by lane -> packets):
+    // 7.6 0.293 -> 0.227, 5.1 0.147 -> 0.126, 3.8 0.096 -> 0.094, 3.2 0.070 -> 0.078, 2.5 0.046 -> 0.069; the teapot (ratio 13 and up)
+    // gains or breaks even down to 480 x 270
+    return tri >= 4.0 * pixel;   // NaN (degenerate box or camera): false
 }
 
 // Room for the rebased copies of the scene's inner-node records, one per pipeline slot.
@@ -788,7 +793,8 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     ahead_discard(c);  // this launch takes a staging slot of its own
-    int rc = ensure_paths_buffers(c, p->width, p->height);
+    const bool packets = use_packets(c, p, dc);
+    int rc = ensure_paths_buffers(c, p->width, p->height, packets);
     if (rc != RT_OK) return rc;
     // counters and per-kernel timing are read on the context's stream: such calls stay on it
     if (count || c->profiling || c->tune_overlap == 0) pipelined = false;
@@ -813,7 +819,6 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
         c->ahead.unjoined = 0;  // pst is the context's stream
     }
     if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
-    const bool packets = use_packets(c, p, dc);
     if (packets && (rc = ensure_rnodes(c)) != RT_OK) return rc;
     if (packets && pipelined) {
         if ((rc = launch_k_primary_pipelined(c, dc, a, slot, pst)) != RT_OK) return rc;
@@ -905,7 +910,7 @@ static int frame_call(rt_context* c, const DCamera& dc, const rt_params* p, uint
     if (!ah.valid) {
         const uint32_t k = cap;
         if (k < 2u) return launch_paths_batch(c, dc, p, frame_count, 1u, 1u, prev, out, true);
-        if ((rc = ensure_paths_buffers(c, p->width, p->height)) != RT_OK) return rc;
+        if ((rc = ensure_paths_buffers(c, p->width, p->height, use_packets(c, p, dc))) != RT_OK) return rc;
         ah.base = frame_count;
         ah.count = k;
         ah.slot = c->lane_next++ % RT_LANES;
