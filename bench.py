@@ -646,5 +646,15 @@ def cpu_baseline(pkg, scene, cam, W, H, budget_s):
     }
 
 
+def _only_the_json_line_on_stdout():
+    """Libraries loaded later write banners to file descriptor 1 (RCCL prints its version block there at start-up): from here on
+    descriptor 1 is the terminal's stderr, and sys.stdout -- what main() prints its one JSON line to -- keeps the real one."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real, "w", buffering=1)
+
+
 if __name__ == "__main__":
+    _only_the_json_line_on_stdout()
     sys.exit(main())

@@ -54,7 +54,8 @@ def _run_bench(extra, launcher=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    # the JSON line and nothing else on stdout -- also under the launcher, where RCCL writes its version block to descriptor 1
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     return json.loads(lines[0])
 
