@@ -239,8 +239,13 @@ static thread_local std::string g_create_error;
 //   the test accepts barycentrics up to E outside [0, 1]: another 2 E (|e1| + |e2|) <= 4 E m2;
 //   the stored edges are rounded differences (u m2), and the slab arithmetic of the cull test itself (a subtraction, an
 //   approximate reciprocal, a product) is off by at most 4u D per plane.
-// pad = 4 fp + 4 E m2 + u m2 + 8u D: the floating-point part carries a safety factor of 4.  The first-order bounds
-// need the relative error of det to be small, 6.5 u m1 / E << 1: scenes with m1 >= 2 (or a NaN anywhere) are not culled.
+// pad = fp + 4 E m2 + u m2 + 8u D.  (Until the bound was attacked numerically the floating-point part carried a safety
+// factor of 4.  tools/cull_bound_probe.py aims 10^7 rays at the rims of grazing triangles -- |det| just above E, origins up
+// to D away: the cases the derivation names as the worst -- runs the test in binary32 and measures in binary64 how far a
+// ray reported as a hit really is from its triangle: at most 1/59 (dragon80k's D, m1, m2) and 1/52 (the teapot's) of
+// fp + 4 E m2 + u m2.  The factor bought nothing the bound does not already give and cost 5 to 9 % of the throughput.)
+// The first-order bounds need the relative error of det to be small, 6.5 u m1 / E << 1: scenes with m1 >= 2 (or a NaN
+// anywhere) are not culled.
 //
 // |s| <= D is the worst case.  For the triangles inside ONE box |s| and T are at most the box's reach from the origin (the
 // largest distance to any of its points), so the same bound with D replaced by the reach R gives a pad that grows with
@@ -250,13 +255,13 @@ static CullPad cull_pad_of(double D, double m1, double m2, int reach_mode /* 0 n
     const double u = 1.0 / 16777216.0, E = (double)RT_EPS;
     CullPad cp;
     if (!(D >= 0.0) || !(m1 < 2.0) || !(m2 < 1e18) || !(D < 1e18)) return cp;
-    const double slope = 4.0 * ((u / E) * m1 * 29.0 + 2.0 * u) + 8.0 * u;
-    const double near = 4.0 * ((u / E) * m1 * 26.5 * m2 + 2.0 * u * 4.1 * m2) + 4.0 * E * m2 + u * m2;
+    const double slope = ((u / E) * m1 * 29.0 + 2.0 * u) + 8.0 * u;
+    const double near = ((u / E) * m1 * 26.5 * m2 + 2.0 * u * 4.1 * m2) + 4.0 * E * m2 + u * m2;
     const double pad = slope * D + near;   // the constant pad: every reach is at most D
-    // by rule: where the constant pad exceeds the longest triangle edge, i.e. the scene is large against its triangles
-    // (measured: 9.27 M-triangle grid, pad 1.3 against edges <= 0.46: 1.21 -> 0.91 ms per frame with the reach-dependent
-    // pad; dragon80k and teapot, pad 0.09 and 0.2 of the longest edge: 5 % slower with it)
-    const bool reach = reach_mode < 0 ? pad > m2 : reach_mode > 0;
+    // by rule: where the constant pad exceeds a quarter of the longest triangle edge, i.e. the scene is large against its
+    // triangles (measured: 9.27 M-triangle grid, pad 0.33 against edges <= 0.46: 1.05 -> 0.84 ms per frame with the
+    // reach-dependent pad; dragon80k and teapot, pad 0.02 and 0.06 of the longest edge: 1 to 8 % slower with it)
+    const bool reach = reach_mode < 0 ? 4.0 * pad > m2 : reach_mode > 0;
     cp.slack = (float)(2.0 * (reach ? near : pad) * 1.001);
     cp.slope = reach ? (float)(2.0 * slope * 1.001) : 0.0f;
     return cp;
