@@ -149,6 +149,9 @@ struct rt_context {
     // pipeline slot like the staged samples
     float4* d_rnodes = nullptr;   // rebased inner-node records (k_rebase), one copy of rnodes_cap records per pipeline slot;
     size_t rnodes_cap = 0;        // allocated by the first launch that traces packets, kept while the scene's records fit
+    float4* d_rtris = nullptr;    // rebased triangle records (k_rebase_tris), likewise
+    size_t rtris_cap = 0;
+    size_t num_tri_recs = 0;      // triangle records of the current scene (leaf-ordered; a malformed tree's overlapping leaves repeat triangles)
     size_t num_recs = 0;          // inner-node records of the current scene
     float4* d_hitq = nullptr;
     uint32_t* d_hcount = nullptr;
@@ -320,6 +323,8 @@ static void free_ref(rt_context* c) {
 static void free_scene(rt_context* c) {
     dfree(c->d_rnodes);
     c->rnodes_cap = 0;
+    dfree(c->d_rtris);
+    c->rtris_cap = 0;
     dfree(c->d_nodes);
     dfree(c->d_tris);
     dfree(c->d_shade);
@@ -592,6 +597,7 @@ static void fill_paths_args(const rt_context* c, const rt_params* p, const BandL
     if (c->tune_cache >= 0 && c->tune_cache < a.cache_recs) a.cache_recs = c->tune_cache;
     a.hits = nullptr;
     a.rnodes = nullptr;
+    a.rtris = nullptr;
     a.pk_ctr = nullptr;
     a.pk_chunk = 1;
     a.finite_boxes = c->finite_boxes && c->tune_signed_slabs ? 1u : 0u;
@@ -683,17 +689,26 @@ static bool use_packets(const rt_context* c, const rt_params* p, const DCamera& 
     return tri >= 4.0 * pixel;   // NaN (degenerate box or camera): false
 }
 
-// Room for the rebased copies of the scene's inner-node records, one per pipeline slot.
+// Room for the rebased copies of the scene's inner-node and triangle records, one per pipeline slot.
 static int ensure_rnodes(rt_context* c) {
-    if (c->num_recs <= c->rnodes_cap && c->d_rnodes) return RT_OK;
+    if (c->num_recs <= c->rnodes_cap && c->d_rnodes && c->num_tri_recs <= c->rtris_cap && c->d_rtris) return RT_OK;
     ahead_reset(c);   // launches in flight may still read the old copies
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < RT_LANES; k++) HIPCHK(c, hipStreamSynchronize(c->lane_stream[k]));
-    dfree(c->d_rnodes);
-    c->rnodes_cap = 0;
-    const size_t cap = c->num_recs + c->num_recs / 16 + 1;   // a rebuilt tree's record count wanders a little
-    HIPCHK(c, hipMalloc(&c->d_rnodes, cap * RT_LANES * 4 * sizeof(float4)));
-    c->rnodes_cap = cap;
+    if (!(c->num_recs <= c->rnodes_cap && c->d_rnodes)) {
+        dfree(c->d_rnodes);
+        c->rnodes_cap = 0;
+        const size_t cap = c->num_recs + c->num_recs / 16 + 1;   // a rebuilt tree's record count wanders a little
+        HIPCHK(c, hipMalloc(&c->d_rnodes, cap * RT_LANES * 4 * sizeof(float4)));
+        c->rnodes_cap = cap;
+    }
+    if (!(c->num_tri_recs <= c->rtris_cap && c->d_rtris)) {
+        dfree(c->d_rtris);
+        c->rtris_cap = 0;
+        const size_t cap = c->num_tri_recs + 1;
+        HIPCHK(c, hipMalloc(&c->d_rtris, cap * RT_LANES * 4 * sizeof(float4)));
+        c->rtris_cap = cap;
+    }
     return RT_OK;
 }
 
@@ -704,11 +719,16 @@ static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& 
     // records as they are)
     float4* const rn = c->d_rnodes + (size_t)slot * c->rnodes_cap * 4;
     a.rnodes = rn;
+    float4* const rt = c->d_rtris + (size_t)slot * c->rtris_cap * 4;
+    a.rtris = rt;
     if (!count && c->num_recs) {
         const uint32_t quads = (uint32_t)(c->num_recs * 4);
         hipLaunchKernelGGL(k_rebase, dim3((quads + 255u) / 256u), dim3(256), 0, st, (const float4*)c->d_nodes, rn, quads, dc.pos[0], dc.pos[1],
                            dc.pos[2]);
     }
+    if (!count && c->num_tri_recs)
+        hipLaunchKernelGGL(k_rebase_tris, dim3((unsigned)((c->num_tri_recs + 255u) / 256u)), dim3(256), 0, st, (const float4*)c->d_tris, rt,
+                           (uint32_t)c->num_tri_recs, dc.pos[0], dc.pos[1], dc.pos[2]);
     const size_t share = c->hitq_items / RT_LANES;
     a.hitq = c->d_hitq + (size_t)slot * share * 64;
     a.hcount = c->d_hcount + (size_t)slot * share;
@@ -1321,6 +1341,7 @@ int rt_upload_scene(rt_context* c, const rt_scene* s) {
     }
 
     c->num_recs = nrec;
+    c->num_tri_recs = ntri;
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
     c->sc.shade = c->d_shade;
@@ -1512,6 +1533,7 @@ static int build_core(rt_context* c) {
     bd.cur = cur;
     bd.parents_valid = false;
     c->num_recs = (size_t)num_recs;
+    c->num_tri_recs = (size_t)nf;
     c->sc.nodes = c->d_nodes;
     c->sc.tris = c->d_tris;
     c->sc.shade = c->d_shade;

@@ -69,6 +69,24 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
 // The text comes in three pieces -- up to the arrival of an inner node's record, the two slab tests (which leave the
 // distances to child 1 / child 2 in v51 / v52: the reference's value when the ray meets the box, +inf otherwise), and
 // everything after them -- and PK_DEFINE_TRAVERSE makes one function per form of the slab tests.
+// The same for the triangle test (raytrace.glsl:79-110): with one origin for all rays of the launch, s = o - a,
+// q = cross(s, e1) and dot(e2, q) -- the numerator of t -- are per-triangle constants.  k_rebase_tris computes them once
+// per launch, in binary32 with the operations and their order of tri_dist_flat, into a copy of the triangle records laid out
+// (e1 flags)(e2 id)(s, dot(e2, q))(q -): 17 of the 54 vector instructions of a packet's triangle test, and one 64-byte
+// scalar load instead of two loads.
+__global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4* out, uint32_t num_tris, float ox, float oy, float oz) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= num_tris) return;
+    const float4 t0 = tris[(size_t)i * 4u], t1 = tris[(size_t)i * 4u + 1u], t2 = tris[(size_t)i * 4u + 2u];
+    const rt_vec3 e1 = rt_v3(t1.x, t1.y, t1.z), e2 = rt_v3(t2.x, t2.y, t2.z);
+    const rt_vec3 s = rt_sub(rt_v3(ox, oy, oz), rt_v3(t0.x, t0.y, t0.z));
+    const rt_vec3 q = rt_cross(s, e1);
+    out[(size_t)i * 4u] = make_float4(e1.x, e1.y, e1.z, t0.w);
+    out[(size_t)i * 4u + 1u] = make_float4(e2.x, e2.y, e2.z, t1.w);
+    out[(size_t)i * 4u + 2u] = make_float4(s.x, s.y, s.z, rt_dot(e2, q));
+    out[(size_t)i * 4u + 3u] = make_float4(q.x, q.y, q.z, 0.0f);
+}
+
 #define PK_STR2(x) #x
 #define PK_STR(x) PK_STR2(x)
 // diagnostic builds: PK_PAD_V vector / PK_PAD_S scalar no-ops per inner-node visit, to measure what an instruction there costs
@@ -241,61 +259,42 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
         "s_mov_b32 s70, s69\n\t"                                                                                       \
         "s_mov_b64 exec, s[66:67]\n\t"                                                                                 \
         "s_branch Lnode%=\n"                                                                                           \
-        /* ---- leaf: triangle records (a flags)(e1 id)(e2 -), the last one of the leaf has flag bit 0 */              \
+        /* ---- leaf: the launch's rebased triangle records, the last one of the leaf has flag bit 0 */              \
         "Lleaf%=:\n\t"                                                                                                 \
         "s_cmp_eq_u32 s70, 0x80000001\n\t"                                                                             \
         "s_cbranch_scc1 Lpop%=\n\t"                                                                                    \
         "s_not_b32 s72, s70\n\t"                                                                                       \
         "s_lshl_b32 s72, s72, 6\n"                                                                                     \
         "Ltri%=:\n\t"                                                                                                  \
-        "s_load_dwordx8 s[36:43], %[tris], s72\n\t"                                                                    \
-        "s_add_u32 s73, s72, 32\n\t"                                                                                   \
-        "s_load_dwordx4 s[44:47], %[tris], s73\n\t"                                                                    \
+        "s_load_dwordx16 s[36:51], %[tris], s72\n\t" /* (e1 flags)(e2 id)(o - a, dot(e2, q))(q = cross(o - a, e1), -): k_rebase_tris */ \
         "s_add_u32 s72, s72, 64\n\t"                                                                                   \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_mul_f32_e32 v40, s46, %[dy]\n\t"                                                                            \
-        "v_mul_f32_e32 v41, s45, %[dz]\n\t"                                                                            \
-        "v_mul_f32_e32 v42, s44, %[dz]\n\t"                                                                            \
-        "v_mul_f32_e32 v43, s46, %[dx]\n\t"                                                                            \
-        "v_mul_f32_e32 v44, s45, %[dx]\n\t"                                                                            \
-        "v_mul_f32_e32 v45, s44, %[dy]\n\t"                                                                            \
+        "v_mul_f32_e32 v40, s42, %[dy]\n\t"                                                                            \
+        "v_mul_f32_e32 v41, s41, %[dz]\n\t"                                                                            \
+        "v_mul_f32_e32 v42, s40, %[dz]\n\t"                                                                            \
+        "v_mul_f32_e32 v43, s42, %[dx]\n\t"                                                                            \
+        "v_mul_f32_e32 v44, s41, %[dx]\n\t"                                                                            \
+        "v_mul_f32_e32 v45, s40, %[dy]\n\t"                                                                            \
         "v_sub_f32_e32 v40, v40, v41\n\t" /* p = cross(d, e2) */                                                       \
         "v_sub_f32_e32 v41, v42, v43\n\t"                                                                              \
         "v_sub_f32_e32 v42, v44, v45\n\t"                                                                              \
-        "v_subrev_f32_e32 v43, s36, %[ox]\n\t" /* s = o - a */                                                         \
-        "v_subrev_f32_e32 v44, s37, %[oy]\n\t"                                                                         \
-        "v_subrev_f32_e32 v45, s38, %[oz]\n\t"                                                                         \
-        "v_mul_f32_e32 v46, s40, v40\n\t"                                                                              \
-        "v_mul_f32_e32 v47, s41, v41\n\t"                                                                              \
-        "v_mul_f32_e32 v48, s42, v42\n\t"                                                                              \
-        "v_mul_f32_e32 v40, v43, v40\n\t"                                                                              \
-        "v_mul_f32_e32 v41, v44, v41\n\t"                                                                              \
-        "v_mul_f32_e32 v42, v45, v42\n\t"                                                                              \
-        "v_mul_f32_e32 v49, s42, v44\n\t"                                                                              \
-        "v_mul_f32_e32 v50, s41, v45\n\t"                                                                              \
-        "v_mul_f32_e32 v45, s40, v45\n\t"                                                                              \
-        "v_mul_f32_e32 v51, s42, v43\n\t"                                                                              \
-        "v_mul_f32_e32 v43, s41, v43\n\t"                                                                              \
-        "v_mul_f32_e32 v44, s40, v44\n\t"                                                                              \
+        "v_mul_f32_e32 v46, s36, v40\n\t"                                                                              \
+        "v_mul_f32_e32 v47, s37, v41\n\t"                                                                              \
+        "v_mul_f32_e32 v48, s38, v42\n\t"                                                                              \
+        "v_mul_f32_e32 v40, s44, v40\n\t"                                                                              \
+        "v_mul_f32_e32 v41, s45, v41\n\t"                                                                              \
+        "v_mul_f32_e32 v42, s46, v42\n\t"                                                                              \
         "v_add_f32_e32 v46, v46, v47\n\t"                                                                              \
         "v_add_f32_e32 v40, v40, v41\n\t"                                                                              \
-        "v_sub_f32_e32 v41, v49, v50\n\t" /* q = cross(s, e1) */                                                       \
-        "v_sub_f32_e32 v45, v45, v51\n\t"                                                                              \
-        "v_sub_f32_e32 v43, v43, v44\n\t"                                                                              \
         "v_add_f32_e32 v44, v48, v46\n\t" /* det = dot(e1, p) */                                                       \
-        "v_add_f32_e32 v40, v42, v40\n\t" /* dot(s, p) */                                                              \
-        "v_mul_f32_e32 v42, %[dx], v41\n\t"                                                                            \
-        "v_mul_f32_e32 v46, %[dy], v45\n\t"                                                                            \
-        "v_mul_f32_e32 v41, s44, v41\n\t"                                                                              \
-        "v_mul_f32_e32 v45, s45, v45\n\t"                                                                              \
+        "v_add_f32_e32 v40, v42, v40\n\t" /* dot(o - a, p) */                                                          \
+        "v_mul_f32_e32 v42, s48, %[dx]\n\t"                                                                            \
+        "v_mul_f32_e32 v46, s49, %[dy]\n\t"                                                                            \
         "v_div_scale_f32 v48, s[78:79], v44, v44, 1.0\n\t" /* inv_det = 1 / det, correctly rounded */                  \
-        "v_add_f32_e32 v41, v41, v45\n\t"                                                                              \
         "v_rcp_f32_e32 v45, v48\n\t"                                                                                   \
-        "v_mul_f32_e32 v47, %[dz], v43\n\t"                                                                            \
-        "v_mul_f32_e32 v43, s46, v43\n\t"                                                                              \
-        "v_add_f32_e32 v41, v43, v41\n\t" /* dot(e2, q) */                                                             \
-        "v_fma_f32 v43, -v48, v45, 1.0\n\t"                                                                            \
+        "v_mul_f32_e32 v47, s50, %[dz]\n\t"                                                                            \
         "v_div_scale_f32 v49, vcc, 1.0, v44, 1.0\n\t"                                                                  \
+        "v_fma_f32 v43, -v48, v45, 1.0\n\t"                                                                            \
         "v_fmac_f32_e32 v45, v43, v45\n\t"                                                                             \
         "v_mul_f32_e32 v43, v49, v45\n\t"                                                                              \
         "v_add_f32_e32 v42, v42, v46\n\t"                                                                              \
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
         "v_mul_f32_e32 v40, v40, v43\n\t" /* u */                                                                      \
         "s_and_b32 s77, s39, 1\n\t"                                                                                    \
         "v_mul_f32_e32 v42, v42, v43\n\t" /* v */                                                                      \
-        "v_mul_f32_e32 v41, v41, v43\n\t" /* t */                                                                      \
+        "v_mul_f32_e32 v41, s47, v43\n\t" /* t = dot(e2, q) / det */                                                   \
         "v_cmp_gt_f32_e32 vcc, 0, v40\n\t"                                                                             \
         "v_cmp_gt_f32_e64 s[80:81], |v40|, s76\n\t"                                                                    \
         "v_add_f32_e32 v43, -1.0, v40\n\t"                                                                             \
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene s
                 const bool ux = (px & in0) == in0 || (nx & in0) == in0, uy = (py & in0) == in0 || (ny & in0) == in0, uz = (pz & in0) == in0 || (nz & in0) == in0;
                 if (ux && uy && uz) form = ((nx & in0) == in0 ? 1 : 0) | ((ny & in0) == in0 ? 2 : 0) | ((nz & in0) == in0 ? 4 : 0);
             }
-#define PK_GO(F_) gave_up = F_((unsigned long long)(uintptr_t)a.rnodes, (unsigned long long)(uintptr_t)sc.tris, sc.root_ref, in0, o, d, inv, lrow, best, best_id)
+#define PK_GO(F_) gave_up = F_((unsigned long long)(uintptr_t)a.rnodes, (unsigned long long)(uintptr_t)a.rtris, sc.root_ref, in0, o, d, inv, lrow, best, best_id)
             switch (form) {
                 case 0: PK_GO(pk_traverse_ppp); break;
                 case 1: PK_GO(pk_traverse_npp); break;

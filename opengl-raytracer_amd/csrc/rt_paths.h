@@ -95,6 +95,7 @@ struct PathsArgs {
     float2* hits;                   // [pixels] closest hit of every pixel's primary ray, (t, id bits): written in PM_PRIMARY, read in PM_REUSE
     float4* hitq;                   // [total_tiles][64] PM_QUEUE: (t, id bits, lane bits, 0) of the k-th primary ray of the item that hit something
     const float4* rnodes;           // k_primary: the inner-node records with the launch's ray origin subtracted from every box corner (k_rebase)
+    const float4* rtris;            // k_primary: the triangle records rebased to the launch's ray origin (k_rebase_tris)
     uint32_t* pk_ctr;               // k_primary: its chunk counters, 16 words apart, set at launch (see k_primary)
     uint32_t pk_chunk;              // k_primary: items per grab
     uint32_t finite_boxes;          // k_primary: every box of the tree is finite (the sign-specific slab tests may be used)
