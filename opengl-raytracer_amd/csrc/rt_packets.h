@@ -42,7 +42,7 @@ typedef const __attribute__((address_space(4))) pk_f4* pk_cf4;   // constant add
 
 // The primary rays of a launch leave one point, so the first half of every slab test -- box corner minus ray origin
 // (raytrace.glsl:115-116) -- is the same for all of them: k_rebase does those subtractions once per launch, into a copy of the
-// inner-node records that k_primary<false> reads (12 of the ~66 vector instructions of a packet's node visit).  The same
+// inner-node records that k_primary<false> reads (12 vector instructions of a packet's node visit).  The same
 // binary32 subtraction, done earlier: results are bit-identical.
 __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out, uint32_t num_quads, float ox, float oy, float oz) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -66,9 +66,8 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
 // instruction order are the compiler's own output for box_dist / tri_dist_flat, so results are bit-identical.
 // `nodes` are the launch's rebased records (k_rebase: box corners minus the common ray origin); the triangle test still
 // needs the origin.  Registers s36-s77 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
-// The text comes in three pieces -- up to the arrival of an inner node's record, the two slab tests (which leave the
-// distances to child 1 / child 2 in v51 / v52: the reference's value when the ray meets the box, +inf otherwise), and
-// everything after them -- and PK_DEFINE_TRAVERSE makes one function per form of the slab tests.
+// The text comes in three pieces -- up to the arrival of an inner node's record, the two slab tests (which leave tNear
+// of child 1 / child 2 in v51 / v52 and tFar in v50 / v54, raytrace.glsl:117-120), and everything after them -- and PK_DEFINE_TRAVERSE makes one function per form of the slab tests.
 // The same for the triangle test (raytrace.glsl:79-110): with one origin for all rays of the launch, s = o - a,
 // q = cross(s, e1) and dot(e2, q) -- the numerator of t -- are per-triangle constants.  k_rebase_tris computes them once
 // per launch, in binary32 with the operations and their order of tri_dist_flat, into a copy of the triangle records laid out
@@ -131,41 +130,28 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
         "v_max_f32_e32 v40, v40, v43\n\t"                                                                              \
         "v_max_f32_e32 v41, v41, v44\n\t"                                                                              \
         "v_max_f32_e32 v42, v42, v45\n\t"                                                                              \
-        "v_max3_f32 v49, v46, v47, v48\n\t" /* tNear */                                                                \
+        "v_max3_f32 v51, v46, v47, v48\n\t" /* tNear of child 1 */                                                     \
         "v_min3_f32 v50, v40, v41, v42\n\t" /* tFar */                                                                 \
-        "v_cmp_lt_f32_e64 s[80:81], s76, v49\n\t" /* EPS < tNear */                                                    \
         "v_mul_f32_e32 v40, s42, %[ix]\n\t"                                                                            \
         "v_mul_f32_e32 v41, s43, %[iy]\n\t"                                                                            \
         "v_mul_f32_e32 v42, s44, %[iz]\n\t"                                                                            \
         "v_mul_f32_e32 v43, s45, %[ix]\n\t"                                                                            \
         "v_mul_f32_e32 v44, s46, %[iy]\n\t"                                                                            \
         "v_mul_f32_e32 v45, s47, %[iz]\n\t"                                                                            \
-        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t" /* tFar >= tNear */                                                       \
-        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t" /* EPS < tFar */                                                     \
-        "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"                                                                  \
         "v_min_f32_e32 v46, v40, v43\n\t"                                                                              \
         "v_min_f32_e32 v47, v41, v44\n\t"                                                                              \
         "v_min_f32_e32 v48, v42, v45\n\t"                                                                              \
         "v_max_f32_e32 v40, v40, v43\n\t"                                                                              \
         "v_max_f32_e32 v41, v41, v44\n\t"                                                                              \
         "v_max_f32_e32 v42, v42, v45\n\t"                                                                              \
-        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
-        "v_max3_f32 v49, v46, v47, v48\n\t"                                                                            \
-        "v_min3_f32 v50, v40, v41, v42\n\t"                                                                            \
-        "v_cndmask_b32_e32 v51, v60, v51, vcc\n\t" /* d1 = hit ? (tNear > EPS ? tNear : 0) : inf */                    \
-        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"                                                                           \
-        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t"                                                                      \
-        "v_cmp_lt_f32_e64 s[80:81], s76, v49\n\t"                                                                      \
-        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
-        "s_nop 0\n\t"                                                                                                  \
-        "v_cndmask_b32_e64 v52, 0, v49, s[80:81]\n\t"                                                                  \
-        "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t" /* d2 */
+        "v_max3_f32 v52, v46, v47, v48\n\t" /* tNear of child 2 */                                                     \
+        "v_min3_f32 v54, v40, v41, v42\n\t" /* tFar */
 
 // The slab tests for a packet whose rays all point the same way along every axis (and have finite reciprocals), on a tree
 // whose boxes are finite and not inverted (min <= max): with 1/d > 0 the product with the box's lower corner is the smaller of the two (rounding is
 // monotonic, and lo - o <= hi - o), with 1/d < 0 the one with the upper corner, so the min and max of raytrace.glsl:117-118
-// are known in advance and 12 of the 38 vector instructions go away.  Same values, hence same distances, as the general
-// form (a zero may differ in sign where both products are zeros; the distance handed on is then the literal 0 either way).
+// are known in advance and 12 of the 28 vector instructions go away.  Same values as the general form (a zero may differ
+// in sign where both products are zeros, which no comparison tells apart).
 // n1x = the register holding child 1's NEAR plane along x for this direction, f1x its far plane, and so on.
 #define PK_ASM_SLAB_SIGNED(n1x, f1x, n2x, f2x, n1y, f1y, n2y, f2y, n1z, f1z, n2z, f2z) \
         "v_mul_f32_e32 v40, " n1x ", %[ix]\n\t"                                                                        \
@@ -174,7 +160,7 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
         "v_mul_f32_e32 v43, " f1x ", %[ix]\n\t"                                                                        \
         "v_mul_f32_e32 v44, " f1y ", %[iy]\n\t"                                                                        \
         "v_mul_f32_e32 v45, " f1z ", %[iz]\n\t"                                                                        \
-        "v_max3_f32 v49, v40, v41, v42\n\t" /* tNear of child 1 */                                                     \
+        "v_max3_f32 v51, v40, v41, v42\n\t" /* tNear of child 1 */                                                     \
         "v_min3_f32 v50, v43, v44, v45\n\t" /* tFar */                                                                 \
         "v_mul_f32_e32 v46, " n2x ", %[ix]\n\t"                                                                        \
         "v_mul_f32_e32 v47, " n2y ", %[iy]\n\t"                                                                        \
@@ -182,21 +168,8 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
         "v_mul_f32_e32 v40, " f2x ", %[ix]\n\t"                                                                        \
         "v_mul_f32_e32 v41, " f2y ", %[iy]\n\t"                                                                        \
         "v_mul_f32_e32 v42, " f2z ", %[iz]\n\t"                                                                        \
-        "v_cmp_ge_f32_e32 vcc, v50, v49\n\t"                                                                           \
-        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t"                                                                      \
-        "v_cmp_lt_f32_e64 s[80:81], s76, v49\n\t"                                                                      \
-        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
-        "v_max3_f32 v53, v46, v47, v48\n\t" /* tNear of child 2 */                                                     \
-        "v_min3_f32 v54, v40, v41, v42\n\t"                                                                            \
-        "v_cndmask_b32_e64 v51, 0, v49, s[80:81]\n\t"                                                                  \
-        "v_cndmask_b32_e32 v51, v60, v51, vcc\n\t" /* d1 */                                                            \
-        "v_cmp_ge_f32_e32 vcc, v54, v53\n\t"                                                                           \
-        "v_cmp_lt_f32_e64 s[78:79], s76, v54\n\t"                                                                      \
-        "v_cmp_lt_f32_e64 s[80:81], s76, v53\n\t"                                                                      \
-        "s_and_b64 vcc, vcc, s[78:79]\n\t"                                                                             \
-        "s_nop 0\n\t"                                                                                                  \
-        "v_cndmask_b32_e64 v52, 0, v53, s[80:81]\n\t"                                                                  \
-        "v_cndmask_b32_e32 v52, v60, v52, vcc\n\t" /* d2 */
+        "v_max3_f32 v52, v46, v47, v48\n\t" /* tNear of child 2 */                                                     \
+        "v_min3_f32 v54, v40, v41, v42\n\t" /* tFar */
 #define PK_ASM_SLAB_EXPAND(...) PK_ASM_SLAB_SIGNED(__VA_ARGS__)
 #define PK_XP "s36", "s39", "s42", "s45"   /* rays go up the x axis: near planes are the boxes' lower x, far planes the upper */
 #define PK_XN "s39", "s36", "s45", "s42"
@@ -205,60 +178,77 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
 #define PK_ZP "s38", "s41", "s44", "s47"
 #define PK_ZN "s41", "s38", "s47", "s44"
 
+// One order of descent, written out for each of the two (so that nothing has to be selected by the order at run time):
+// ref1 / lanes1 / dist1 = the child the wave enters first, the lanes that want it and their tNear; ref2 / s[l2_lo:l2_hi] / dist2
+// the other child; s[dis_lo:dis_hi] = the lanes that want both but in the other order.  They leave the wave here and come back
+// for the first child after the second (pushed below it), which keeps every lane's own visit order.
+#define PK_ASM_DESCEND(ref1, ref2, lanes1, l2_lo, l2_hi, dist1, dist2, dis_lo, dis_hi, tag) \
+        "s_andn2_b64 s[64:65], " lanes1 ", s[" dis_lo ":" dis_hi "]\n\t" /* the lanes that enter the first child now */   \
+        "s_cbranch_scc0 Lswap" tag "%=\n\t"                                                                             \
+        "s_cmp_gt_u32 s71, %[room]\n\t"                                                                                 \
+        "s_cbranch_scc1 Lgiveup%=\n\t"                                                                                  \
+        "s_cmp_eq_u64 s[" dis_lo ":" dis_hi "], 0\n\t"                                                                  \
+        "s_cbranch_scc1 Lnodis" tag "%=\n\t"                                                                            \
+        "s_mov_b32 m0, s71\n\t"                                                                                         \
+        "s_nop 0\n\t"                                                                                                   \
+        "v_writelane_b32 v57, " ref1 ", m0\n\t"                                                                         \
+        "v_writelane_b32 v58, s" dis_lo ", m0\n\t"                                                                      \
+        "v_writelane_b32 v59, s" dis_hi ", m0\n\t"                                                                      \
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                       \
+        "ds_write_b32 v55, " dist1 "\n\t"                                                                               \
+        "s_add_i32 s71, s71, 1\n"                                                                                        \
+        "Lnodis" tag "%=:\n\t"                                                                                          \
+        "s_cmp_eq_u64 s[" l2_lo ":" l2_hi "], 0\n\t"                                                                    \
+        "s_cbranch_scc1 Lgo" tag "%=\n\t"                                                                               \
+        "s_mov_b32 m0, s71\n\t"                                                                                         \
+        "s_nop 0\n\t"                                                                                                   \
+        "v_writelane_b32 v57, " ref2 ", m0\n\t"                                                                         \
+        "v_writelane_b32 v58, s" l2_lo ", m0\n\t"                                                                       \
+        "v_writelane_b32 v59, s" l2_hi ", m0\n\t"                                                                       \
+        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                       \
+        "ds_write_b32 v55, " dist2 "\n\t"                                                                               \
+        "s_add_i32 s71, s71, 1\n"                                                                                        \
+        "Lgo" tag "%=:\n\t"                                                                                             \
+        "s_mov_b32 s70, " ref1 "\n\t"                                                                                   \
+        "s_mov_b64 exec, s[64:65]\n\t"                                                                                  \
+        "s_branch Lnode%=\n"                                                                                             \
+        "Lswap" tag "%=:\n\t" /* nobody enters the first child (then nobody dissents): on to the second */              \
+        "s_cmp_eq_u64 s[" l2_lo ":" l2_hi "], 0\n\t"                                                                    \
+        "s_cbranch_scc1 Lpop%=\n\t"                                                                                     \
+        "s_mov_b32 s70, " ref2 "\n\t"                                                                                   \
+        "s_mov_b64 exec, s[" l2_lo ":" l2_hi "]\n\t"                                                                    \
+        "s_branch Lnode%=\n"
+
 #define PK_ASM_TAIL \
-        /* who wants which child, and in which order (raytrace.glsl:173-190) */                                        \
-        "v_cmp_lt_f32_e64 s[52:53], v51, %[best]\n\t" /* W1 */                                                         \
-        "v_cmp_lt_f32_e64 s[54:55], v52, %[best]\n\t" /* W2 */                                                         \
-        "v_cmp_lt_f32_e64 s[56:57], v51, v52\n\t" /* LT: child 1 first */                                              \
+        /* Who wants which child, and in which order (raytrace.glsl:113-125, 173-190).  The reference's distance to a  \
+           box is d = met ? (tNear > EPS ? tNear : 0) : inf with met = tFar >= tNear && tFar > EPS, and a lane wants a     \
+           child when d < best.  best is +inf or the t of an accepted triangle, which exceeds EPS, so for a box that is    \
+           met d < best <=> tNear < best; d1 < d2 between two met boxes <=> tNear1 < tNear2 && tNear2 > EPS; and the pop   \
+           test `d < best` of a stacked child reads the same with tNear in place of d.  The masks are therefore built      \
+           from tNear and tFar as they are, and d itself is never formed. */                                               \
+        "v_cmp_ge_f32_e32 vcc, v50, v51\n\t" /* tFar1 >= tNear1 */                                                       \
+        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t" /* EPS < tFar1 */                                                      \
+        "v_cmp_lt_f32_e64 s[52:53], v51, %[best]\n\t"                                                                    \
+        "v_cmp_ge_f32_e64 s[80:81], v54, v52\n\t" /* tFar2 >= tNear2 */                                                  \
+        "v_cmp_lt_f32_e64 s[82:83], s76, v54\n\t" /* EPS < tFar2 */                                                      \
+        "v_cmp_lt_f32_e64 s[54:55], v52, %[best]\n\t"                                                                    \
+        "v_cmp_lt_f32_e64 s[56:57], v51, v52\n\t"                                                                        \
+        "v_cmp_lt_f32_e64 s[84:85], s76, v52\n\t" /* EPS < tNear2 */                                                     \
+        "s_and_b64 s[78:79], vcc, s[78:79]\n\t"                                                                          \
+        "s_and_b64 s[80:81], s[80:81], s[82:83]\n\t"                                                                     \
+        "s_and_b64 s[52:53], s[52:53], s[78:79]\n\t" /* W1 */                                                            \
+        "s_and_b64 s[54:55], s[54:55], s[80:81]\n\t" /* W2 */                                                            \
+        "s_and_b64 s[56:57], s[56:57], s[84:85]\n\t" /* LT: child 1 first */                                             \
         "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t" /* both */                                                        \
         "s_and_b64 s[60:61], s[58:59], s[56:57]\n\t" /* both, child 1 first */                                         \
         "s_andn2_b64 s[62:63], s[58:59], s[56:57]\n\t" /* both, child 2 first */                                       \
         "s_bcnt1_i32_b64 s72, s[60:61]\n\t"                                                                            \
         "s_bcnt1_i32_b64 s73, s[62:63]\n\t"                                                                            \
         "s_cmp_gt_u32 s72, s73\n\t" /* scc: the wave takes child 1 first */                                            \
-        "s_cselect_b64 s[64:65], s[52:53], s[54:55]\n\t" /* lanes of the first child */                                \
-        "s_cselect_b64 s[66:67], s[54:55], s[52:53]\n\t" /* lanes of the second child */                               \
-        "s_cselect_b32 s68, s48, s49\n\t" /* first child */                                                            \
-        "s_cselect_b32 s69, s49, s48\n\t" /* second child */                                                           \
-        "s_cselect_b64 s[62:63], s[62:63], s[60:61]\n\t" /* dissenters */                                              \
-        "s_cselect_b64 vcc, -1, 0\n\t"                                                                                 \
-        "v_cndmask_b32_e32 v53, v52, v51, vcc\n\t" /* distances to the first ... */                                    \
-        "v_cndmask_b32_e32 v54, v51, v52, vcc\n\t" /* ... and to the second child */                                   \
-        "s_andn2_b64 s[64:65], s[64:65], s[62:63]\n\t"                                                                 \
-        "s_cbranch_scc0 Lswap%=\n\t"                                                                                   \
-        "s_cmp_gt_u32 s71, %[room]\n\t"                                                                                \
-        "s_cbranch_scc1 Lgiveup%=\n\t"                                                                                 \
-        "s_cmp_eq_u64 s[62:63], 0\n\t"                                                                                 \
-        "s_cbranch_scc1 Lnodis%=\n\t"                                                                                  \
-        "s_mov_b32 m0, s71\n\t" /* the dissenters come back for the first child after the second */                    \
-        "s_nop 0\n\t"                                                                                                  \
-        "v_writelane_b32 v57, s68, m0\n\t"                                                                             \
-        "v_writelane_b32 v58, s62, m0\n\t"                                                                             \
-        "v_writelane_b32 v59, s63, m0\n\t"                                                                             \
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                      \
-        "ds_write_b32 v55, v53\n\t"                                                                                    \
-        "s_add_i32 s71, s71, 1\n"                                                                                      \
-        "Lnodis%=:\n\t"                                                                                                \
-        "s_cmp_eq_u64 s[66:67], 0\n\t"                                                                                 \
-        "s_cbranch_scc1 Lgo%=\n\t"                                                                                     \
-        "s_mov_b32 m0, s71\n\t"                                                                                        \
-        "s_nop 0\n\t"                                                                                                  \
-        "v_writelane_b32 v57, s69, m0\n\t"                                                                             \
-        "v_writelane_b32 v58, s66, m0\n\t"                                                                             \
-        "v_writelane_b32 v59, s67, m0\n\t"                                                                             \
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                      \
-        "ds_write_b32 v55, v54\n\t"                                                                                    \
-        "s_add_i32 s71, s71, 1\n"                                                                                      \
-        "Lgo%=:\n\t"                                                                                                   \
-        "s_mov_b32 s70, s68\n\t"                                                                                       \
-        "s_mov_b64 exec, s[64:65]\n\t"                                                                                 \
-        "s_branch Lnode%=\n"                                                                                           \
-        "Lswap%=:\n\t" /* nobody enters the first child (then nobody dissents): on to the second */                    \
-        "s_cmp_eq_u64 s[66:67], 0\n\t"                                                                                 \
-        "s_cbranch_scc1 Lpop%=\n\t"                                                                                    \
-        "s_mov_b32 s70, s69\n\t"                                                                                       \
-        "s_mov_b64 exec, s[66:67]\n\t"                                                                                 \
-        "s_branch Lnode%=\n"                                                                                           \
+        "s_cbranch_scc0 Lsecond%=\n\t"                                                                                 \
+        PK_ASM_DESCEND("s48", "s49", "s[52:53]", "54", "55", "v51", "v52", "62", "63", "A")                              \
+        "Lsecond%=:\n\t"                                                                                               \
+        PK_ASM_DESCEND("s49", "s48", "s[54:55]", "52", "53", "v52", "v51", "60", "61", "B")                              \
         /* ---- leaf: the launch's rebased triangle records, the last one of the leaf has flag bit 0 */              \
         "Lleaf%=:\n\t"                                                                                                 \
         "s_cmp_eq_u32 s70, 0x80000001\n\t"                                                                             \
