@@ -6,7 +6,17 @@ set -e
 T=$1; OLD=$2
 R=gpurun_out/$T; P=gpurun_out/prof_$T
 [ -n "$OLD" ] && git rm -q --ignore-unmatch "profiles/${OLD}_*"
-cp $R/pmc_traffic.json profiles/pmc_traffic.json
+# each profile_bench.sh run leaves its copy of pmc_traffic.json with its own workload's entry renewed: take every entry from the
+# run that measured it (the two parts of a record start from the same tree, so neither sees the other's entry)
+python3 - $T <<'PY'
+import json, sys
+t = sys.argv[1]
+dst = json.load(open("profiles/pmc_traffic.json"))
+for suffix, key in (("", "dragon80k_1080p"), ("_grid9m", "grid9m_1080p"), ("_grid9m_fix", "grid9m_1080p+fix_invdir")):
+    src = json.load(open(f"gpurun_out/prof_{t}{suffix}/pmc_traffic.json"))
+    dst["workloads"][key] = src["workloads"][key]
+json.dump(dst, open("profiles/pmc_traffic.json", "w"), indent=1)
+PY
 for f in bench_steps20 bench bench_steps20_no_cull bench_frame_loop_steps20 bench_grid9m bench_grid9m_fix; do cp $R/$f.json profiles/${T}_$f.json; done
 cp $R/bench_all_workloads.jsonl profiles/${T}_bench_all_workloads.jsonl
 cp $R/smoke.txt profiles/${T}_smoke.txt
