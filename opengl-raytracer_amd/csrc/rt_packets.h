@@ -101,20 +101,20 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
 #endif
 
 #define PK_ASM_HEAD \
-        "s_mov_b64 s[74:75], exec\n\t"                                                                                 \
-        "s_mov_b32 s76, 0x38d1b717\n\t" /* RT_EPS */                                                                   \
+        "s_mov_b64 s[72:73], exec\n\t"                                                                                 \
+        "v_mov_b32_e32 v53, 0x38d1b717\n\t" /* RT_EPS */                                                                   \
         "v_mov_b32_e32 v60, 0x7f800000\n\t" /* +inf */                                                                 \
-        "s_mov_b32 s71, 0\n\t" /* stack pointer */                                                                     \
+        "s_mov_b32 s69, 0\n\t" /* stack pointer */                                                                     \
         "s_mov_b32 %[gave], 0\n\t"                                                                                     \
-        "s_mov_b32 s70, %[root]\n\t" /* current node */                                                                \
-        "s_and_b64 exec, s[74:75], %[in0]\n\t"                                                                         \
+        "s_mov_b32 s68, %[root]\n\t" /* current node */                                                                \
+        "s_and_b64 exec, s[72:73], %[in0]\n\t"                                                                         \
         "s_cbranch_execz Ldone%=\n"                                                                                    \
         "Lnode%=:\n\t"                                                                                                 \
-        "s_cmp_lt_i32 s70, 0\n\t"                                                                                      \
+        "s_cmp_lt_i32 s68, 0\n\t"                                                                                      \
         "s_cbranch_scc1 Lleaf%=\n\t"                                                                                   \
         /* ---- inner node: record = (c1.min c1.max c2.min c2.max ref1 ref2 - -) */                                    \
-        "s_lshl_b32 s72, s70, 6\n\t"                                                                                   \
-        "s_load_dwordx16 s[36:51], %[nodes], s72\n\t"                                                                  \
+        "s_lshl_b32 s70, s68, 6\n\t"                                                                                   \
+        "s_load_dwordx16 s[36:51], %[nodes], s70\n\t"                                                                  \
         "s_waitcnt lgkmcnt(0)\n\t"
 
 #define PK_ASM_SLAB_ANY \
@@ -185,37 +185,37 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
 #define PK_ASM_DESCEND(ref1, ref2, lanes1, l2_lo, l2_hi, dist1, dist2, dis_lo, dis_hi, tag) \
         "s_andn2_b64 s[64:65], " lanes1 ", s[" dis_lo ":" dis_hi "]\n\t" /* the lanes that enter the first child now */   \
         "s_cbranch_scc0 Lswap" tag "%=\n\t"                                                                             \
-        "s_cmp_gt_u32 s71, %[room]\n\t"                                                                                 \
+        "s_cmp_gt_u32 s69, %[room]\n\t"                                                                                 \
         "s_cbranch_scc1 Lgiveup%=\n\t"                                                                                  \
         "s_cmp_eq_u64 s[" dis_lo ":" dis_hi "], 0\n\t"                                                                  \
         "s_cbranch_scc1 Lnodis" tag "%=\n\t"                                                                            \
-        "s_mov_b32 m0, s71\n\t"                                                                                         \
+        "s_mov_b32 m0, s69\n\t"                                                                                         \
         "s_nop 0\n\t"                                                                                                   \
         "v_writelane_b32 v57, " ref1 ", m0\n\t"                                                                         \
         "v_writelane_b32 v58, s" dis_lo ", m0\n\t"                                                                      \
         "v_writelane_b32 v59, s" dis_hi ", m0\n\t"                                                                      \
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                       \
+        "v_lshl_add_u32 v55, s69, 8, %[lrow]\n\t"                                                                       \
         "ds_write_b32 v55, " dist1 "\n\t"                                                                               \
-        "s_add_i32 s71, s71, 1\n"                                                                                        \
+        "s_add_i32 s69, s69, 1\n"                                                                                        \
         "Lnodis" tag "%=:\n\t"                                                                                          \
         "s_cmp_eq_u64 s[" l2_lo ":" l2_hi "], 0\n\t"                                                                    \
         "s_cbranch_scc1 Lgo" tag "%=\n\t"                                                                               \
-        "s_mov_b32 m0, s71\n\t"                                                                                         \
+        "s_mov_b32 m0, s69\n\t"                                                                                         \
         "s_nop 0\n\t"                                                                                                   \
         "v_writelane_b32 v57, " ref2 ", m0\n\t"                                                                         \
         "v_writelane_b32 v58, s" l2_lo ", m0\n\t"                                                                       \
         "v_writelane_b32 v59, s" l2_hi ", m0\n\t"                                                                       \
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                       \
+        "v_lshl_add_u32 v55, s69, 8, %[lrow]\n\t"                                                                       \
         "ds_write_b32 v55, " dist2 "\n\t"                                                                               \
-        "s_add_i32 s71, s71, 1\n"                                                                                        \
+        "s_add_i32 s69, s69, 1\n"                                                                                        \
         "Lgo" tag "%=:\n\t"                                                                                             \
-        "s_mov_b32 s70, " ref1 "\n\t"                                                                                   \
+        "s_mov_b32 s68, " ref1 "\n\t"                                                                                   \
         "s_mov_b64 exec, s[64:65]\n\t"                                                                                  \
         "s_branch Lnode%=\n"                                                                                             \
         "Lswap" tag "%=:\n\t" /* nobody enters the first child (then nobody dissents): on to the second */              \
         "s_cmp_eq_u64 s[" l2_lo ":" l2_hi "], 0\n\t"                                                                    \
         "s_cbranch_scc1 Lpop%=\n\t"                                                                                     \
-        "s_mov_b32 s70, " ref2 "\n\t"                                                                                   \
+        "s_mov_b32 s68, " ref2 "\n\t"                                                                                   \
         "s_mov_b64 exec, s[" l2_lo ":" l2_hi "]\n\t"                                                                    \
         "s_branch Lnode%=\n"
 
@@ -227,37 +227,37 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
            test `d < best` of a stacked child reads the same with tNear in place of d.  The masks are therefore built      \
            from tNear and tFar as they are, and d itself is never formed. */                                               \
         "v_cmp_ge_f32_e32 vcc, v50, v51\n\t" /* tFar1 >= tNear1 */                                                       \
-        "v_cmp_lt_f32_e64 s[78:79], s76, v50\n\t" /* EPS < tFar1 */                                                      \
+        "v_cmp_lt_f32_e64 s[66:67], v53, v50\n\t" /* EPS < tFar1 */                                                      \
         "v_cmp_lt_f32_e64 s[52:53], v51, %[best]\n\t"                                                                    \
-        "v_cmp_ge_f32_e64 s[80:81], v54, v52\n\t" /* tFar2 >= tNear2 */                                                  \
-        "v_cmp_lt_f32_e64 s[82:83], s76, v54\n\t" /* EPS < tFar2 */                                                      \
+        "s_and_b64 s[66:67], vcc, s[66:67]\n\t"                                                                          \
+        "s_and_b64 s[52:53], s[52:53], s[66:67]\n\t" /* W1 */                                                            \
+        "v_cmp_ge_f32_e32 vcc, v54, v52\n\t" /* tFar2 >= tNear2 */                                                       \
+        "v_cmp_lt_f32_e64 s[66:67], v53, v54\n\t" /* EPS < tFar2 */                                                      \
         "v_cmp_lt_f32_e64 s[54:55], v52, %[best]\n\t"                                                                    \
-        "v_cmp_lt_f32_e64 s[56:57], v51, v52\n\t"                                                                        \
-        "v_cmp_lt_f32_e64 s[84:85], s76, v52\n\t" /* EPS < tNear2 */                                                     \
-        "s_and_b64 s[78:79], vcc, s[78:79]\n\t"                                                                          \
-        "s_and_b64 s[80:81], s[80:81], s[82:83]\n\t"                                                                     \
-        "s_and_b64 s[52:53], s[52:53], s[78:79]\n\t" /* W1 */                                                            \
-        "s_and_b64 s[54:55], s[54:55], s[80:81]\n\t" /* W2 */                                                            \
-        "s_and_b64 s[56:57], s[56:57], s[84:85]\n\t" /* LT: child 1 first */                                             \
+        "s_and_b64 s[66:67], vcc, s[66:67]\n\t"                                                                          \
+        "s_and_b64 s[54:55], s[54:55], s[66:67]\n\t" /* W2 */                                                            \
+        "v_cmp_lt_f32_e32 vcc, v51, v52\n\t"                                                                             \
+        "v_cmp_lt_f32_e64 s[56:57], v53, v52\n\t" /* EPS < tNear2 */                                                     \
+        "s_and_b64 s[56:57], s[56:57], vcc\n\t" /* LT: child 1 first */                                                  \
         "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t" /* both */                                                        \
         "s_and_b64 s[60:61], s[58:59], s[56:57]\n\t" /* both, child 1 first */                                         \
         "s_andn2_b64 s[62:63], s[58:59], s[56:57]\n\t" /* both, child 2 first */                                       \
-        "s_bcnt1_i32_b64 s72, s[60:61]\n\t"                                                                            \
-        "s_bcnt1_i32_b64 s73, s[62:63]\n\t"                                                                            \
-        "s_cmp_gt_u32 s72, s73\n\t" /* scc: the wave takes child 1 first */                                            \
+        "s_bcnt1_i32_b64 s70, s[60:61]\n\t"                                                                            \
+        "s_bcnt1_i32_b64 s71, s[62:63]\n\t"                                                                            \
+        "s_cmp_gt_u32 s70, s71\n\t" /* scc: the wave takes child 1 first */                                            \
         "s_cbranch_scc0 Lsecond%=\n\t"                                                                                 \
         PK_ASM_DESCEND("s48", "s49", "s[52:53]", "54", "55", "v51", "v52", "62", "63", "A")                              \
         "Lsecond%=:\n\t"                                                                                               \
         PK_ASM_DESCEND("s49", "s48", "s[54:55]", "52", "53", "v52", "v51", "60", "61", "B")                              \
         /* ---- leaf: the launch's rebased triangle records, the last one of the leaf has flag bit 0 */              \
         "Lleaf%=:\n\t"                                                                                                 \
-        "s_cmp_eq_u32 s70, 0x80000001\n\t"                                                                             \
+        "s_cmp_eq_u32 s68, 0x80000001\n\t"                                                                             \
         "s_cbranch_scc1 Lpop%=\n\t"                                                                                    \
-        "s_not_b32 s72, s70\n\t"                                                                                       \
-        "s_lshl_b32 s72, s72, 6\n"                                                                                     \
+        "s_not_b32 s70, s68\n\t"                                                                                       \
+        "s_lshl_b32 s70, s70, 6\n"                                                                                     \
         "Ltri%=:\n\t"                                                                                                  \
-        "s_load_dwordx16 s[36:51], %[tris], s72\n\t" /* (e1 flags)(e2 id)(o - a, dot(e2, q))(q = cross(o - a, e1), -): k_rebase_tris */ \
-        "s_add_u32 s72, s72, 64\n\t"                                                                                   \
+        "s_load_dwordx16 s[36:51], %[tris], s70\n\t" /* (e1 flags)(e2 id)(o - a, dot(e2, q))(q = cross(o - a, e1), -): k_rebase_tris */ \
+        "s_add_u32 s70, s70, 64\n\t"                                                                                   \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
         "v_mul_f32_e32 v40, s42, %[dy]\n\t"                                                                            \
         "v_mul_f32_e32 v41, s41, %[dz]\n\t"                                                                            \
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
         "v_add_f32_e32 v40, v42, v40\n\t" /* dot(o - a, p) */                                                          \
         "v_mul_f32_e32 v42, s48, %[dx]\n\t"                                                                            \
         "v_mul_f32_e32 v46, s49, %[dy]\n\t"                                                                            \
-        "v_div_scale_f32 v48, s[78:79], v44, v44, 1.0\n\t" /* inv_det = 1 / det, correctly rounded */                  \
+        "v_div_scale_f32 v48, s[56:57], v44, v44, 1.0\n\t" /* inv_det = 1 / det, correctly rounded */                  \
         "v_rcp_f32_e32 v45, v48\n\t"                                                                                   \
         "v_mul_f32_e32 v47, s50, %[dz]\n\t"                                                                            \
         "v_div_scale_f32 v49, vcc, 1.0, v44, 1.0\n\t"                                                                  \
@@ -295,60 +295,59 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
         "v_div_fixup_f32 v43, v43, v44, 1.0\n\t"                                                                       \
         "v_add_f32_e32 v42, v47, v42\n\t" /* dot(d, q) */                                                              \
         "v_mul_f32_e32 v40, v40, v43\n\t" /* u */                                                                      \
-        "s_and_b32 s77, s39, 1\n\t"                                                                                    \
         "v_mul_f32_e32 v42, v42, v43\n\t" /* v */                                                                      \
         "v_mul_f32_e32 v41, s47, v43\n\t" /* t = dot(e2, q) / det */                                                   \
         "v_cmp_gt_f32_e32 vcc, 0, v40\n\t"                                                                             \
-        "v_cmp_gt_f32_e64 s[80:81], |v40|, s76\n\t"                                                                    \
+        "v_cmp_gt_f32_e64 s[58:59], |v40|, v53\n\t"                                                                    \
         "v_add_f32_e32 v43, -1.0, v40\n\t"                                                                             \
         "v_mov_b32_e32 v61, s43\n\t"                                                                                   \
-        "v_cmp_lt_f32_e64 s[82:83], |v44|, s76\n\t"                                                                    \
-        "v_cmp_lt_f32_e64 s[84:85], 1.0, v40\n\t"                                                                      \
+        "v_cmp_lt_f32_e64 s[60:61], |v44|, v53\n\t"                                                                    \
+        "v_cmp_lt_f32_e64 s[62:63], 1.0, v40\n\t"                                                                      \
         "v_add_f32_e32 v40, v40, v42\n\t"                                                                              \
-        "s_and_b64 s[80:81], vcc, s[80:81]\n\t"                                                                        \
-        "v_cmp_gt_f32_e64 s[86:87], |v43|, s76\n\t"                                                                    \
-        "v_cmp_gt_f32_e64 s[88:89], 0, v42\n\t"                                                                        \
-        "v_cmp_gt_f32_e64 s[52:53], |v42|, s76\n\t"                                                                    \
+        "s_and_b64 s[58:59], vcc, s[58:59]\n\t"                                                                        \
+        "v_cmp_gt_f32_e64 s[64:65], |v43|, v53\n\t"                                                                    \
+        "v_cmp_gt_f32_e64 s[66:67], 0, v42\n\t"                                                                        \
+        "v_cmp_gt_f32_e64 s[52:53], |v42|, v53\n\t"                                                                    \
         "v_cmp_lt_f32_e32 vcc, 1.0, v40\n\t"                                                                           \
         "v_add_f32_e32 v40, -1.0, v40\n\t"                                                                             \
-        "s_or_b64 s[82:83], s[82:83], s[80:81]\n\t"                                                                    \
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                   \
-        "s_and_b64 s[88:89], s[88:89], s[52:53]\n\t"                                                                   \
-        "v_cmp_gt_f32_e64 s[80:81], |v40|, s76\n\t"                                                                    \
-        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"                                                                    \
-        "s_and_b64 s[82:83], vcc, s[80:81]\n\t"                                                                        \
-        "s_or_b64 s[84:85], s[88:89], s[84:85]\n\t"                                                                    \
-        "v_cmp_nlt_f32_e64 s[54:55], s76, v41\n\t"                                                                     \
-        "s_or_b64 s[84:85], s[82:83], s[84:85]\n\t"                                                                    \
-        "s_or_b64 vcc, s[54:55], s[84:85]\n\t"                                                                         \
+        "s_or_b64 s[60:61], s[60:61], s[58:59]\n\t"                                                                    \
+        "s_and_b64 s[62:63], s[62:63], s[64:65]\n\t"                                                                   \
+        "s_and_b64 s[66:67], s[66:67], s[52:53]\n\t"                                                                   \
+        "v_cmp_gt_f32_e64 s[58:59], |v40|, v53\n\t"                                                                    \
+        "s_or_b64 s[62:63], s[60:61], s[62:63]\n\t"                                                                    \
+        "s_and_b64 s[60:61], vcc, s[58:59]\n\t"                                                                        \
+        "s_or_b64 s[62:63], s[66:67], s[62:63]\n\t"                                                                    \
+        "v_cmp_nlt_f32_e64 s[54:55], v53, v41\n\t"                                                                     \
+        "s_or_b64 s[62:63], s[60:61], s[62:63]\n\t"                                                                    \
+        "s_or_b64 vcc, s[54:55], s[62:63]\n\t"                                                                         \
         "v_cndmask_b32_e32 v40, v41, v60, vcc\n\t" /* rejected ? inf : t */                                            \
         "v_cmp_lt_f32_e32 vcc, v40, %[best]\n\t"                                                                       \
-        "s_cmp_eq_u32 s77, 0\n\t"                                                                                      \
+        "s_bitcmp0_b32 s39, 0\n\t" /* scc: not the leaf's last triangle */                                                                                      \
         "s_nop 1\n\t"                                                                                                  \
         "v_cndmask_b32_e32 %[bid], %[bid], v61, vcc\n\t"                                                               \
         "v_cndmask_b32_e32 %[best], %[best], v40, vcc\n\t"                                                             \
         "s_cbranch_scc1 Ltri%=\n"                                                                                      \
         /* ---- next stack entry that still has a lane whose distance to it is below its closest hit (raytrace.glsl:151) */ \
         "Lpop%=:\n\t"                                                                                                  \
-        "s_cmp_eq_u32 s71, 0\n\t"                                                                                      \
+        "s_cmp_eq_u32 s69, 0\n\t"                                                                                      \
         "s_cbranch_scc1 Ldone%=\n\t"                                                                                   \
-        "s_add_i32 s71, s71, -1\n\t"                                                                                   \
+        "s_add_i32 s69, s69, -1\n\t"                                                                                   \
         "s_nop 0\n\t"                                                                                                  \
-        "v_readlane_b32 s78, v58, s71\n\t"                                                                             \
-        "v_readlane_b32 s79, v59, s71\n\t"                                                                             \
-        "s_mov_b64 exec, s[78:79]\n\t"                                                                                 \
-        "v_lshl_add_u32 v55, s71, 8, %[lrow]\n\t"                                                                      \
+        "v_readlane_b32 s56, v58, s69\n\t"                                                                             \
+        "v_readlane_b32 s57, v59, s69\n\t"                                                                             \
+        "s_mov_b64 exec, s[56:57]\n\t"                                                                                 \
+        "v_lshl_add_u32 v55, s69, 8, %[lrow]\n\t"                                                                      \
         "ds_read_b32 v56, v55\n\t"                                                                                     \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
         "v_cmp_lt_f32_e32 vcc, v56, %[best]\n\t"                                                                       \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_scc0 Lpop%=\n\t"                                                                                    \
-        "v_readlane_b32 s70, v57, s71\n\t"                                                                             \
+        "v_readlane_b32 s68, v57, s69\n\t"                                                                             \
         "s_branch Lnode%=\n"                                                                                           \
         "Lgiveup%=:\n\t"                                                                                               \
         "s_mov_b32 %[gave], 1\n"                                                                                       \
         "Ldone%=:\n\t"                                                                                                 \
-        "s_mov_b64 exec, s[74:75]"
+        "s_mov_b64 exec, s[72:73]"
 
 #define PK_DEFINE_TRAVERSE(NAME, SLAB)                                                                                                   \
     __device__ __forceinline__ bool NAME(unsigned long long nodes, unsigned long long tris, int root, unsigned long long in0, rt_vec3 o, \
@@ -359,11 +358,10 @@ __global__ __launch_bounds__(256) void k_rebase_tris(const float4* tris, float4*
             : [nodes] "s"(nodes), [tris] "s"(tris), [root] "s"(root), [in0] "s"(in0), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),                                           \
               [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z), [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z), [lrow] "v"(lrow),                                              \
               [room] "n"(PK_STACK - 2)                                                                                                                                       \
-            : "memory", "vcc", "scc", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",                         \
-              "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",                           \
-              "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88",                           \
-              "s89", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",                           \
-              "v56", "v57", "v58", "v59", "v60", "v61");                                                                                                                     \
+            : "memory", "vcc", "scc", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",             \
+              "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",               \
+              "s70", "s71", "s72", "s73", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",               \
+              "v55", "v56", "v57", "v58", "v59", "v60", "v61");                                                                                                  \
         return gave != 0;                                                                                                                \
     }
 PK_DEFINE_TRAVERSE(pk_traverse_any, PK_ASM_SLAB_ANY)
