@@ -211,6 +211,7 @@ struct rt_context {
     int tune_primary_chunk = 0;                // items a wave of k_primary takes per grab (0: by the launch's number of frames)
     int tune_primary_grid = 0;                 // > 0: k_primary's grid as is (tests of the counter arrangements for grids that are no multiple of 64 or 8)
     int tune_primary_blocks = PK_BLOCKS_PER_CU;  // workgroups per CU of k_primary's grid
+    int tune_primary_joined = 5;                 // ... when the launch starts next to the previous launch's path kernel (RT_TUNE_PRIMARY_JOINED)
     int tune_signed_slabs = 1;                 // k_primary: sign-specific slab tests where a packet's rays allow them (0: A/B runs)
     int tune_packets = 1;                      // primary rays traced tile by tile: 1 by rule (use_packets), 0 never, 2 always (A/B runs)
 
@@ -714,7 +715,7 @@ static int ensure_rnodes(rt_context* c) {
 
 // Points the launch at pipeline slot `slot`'s share of the hit queues and traces the primary rays of its items on `st`;
 // the path kernel that follows on the same stream runs in PM_QUEUE mode.
-static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, bool count, hipStream_t st) {
+static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, bool count, hipStream_t st, bool joins = false) {
     // the slot's copy of the inner-node records, box corners minus this launch's ray origin (the counting build reads the
     // records as they are)
     float4* const rn = c->d_rnodes + (size_t)slot * c->rnodes_cap * 4;
@@ -732,7 +733,10 @@ static void launch_k_primary(const rt_context* c, const DCamera& dc, PathsArgs& 
     const size_t share = c->hitq_items / RT_LANES;
     a.hitq = c->d_hitq + (size_t)slot * share * 64;
     a.hcount = c->d_hcount + (size_t)slot * share;
-    dim3 grid(c->tune_primary_grid > 0 ? c->tune_primary_grid : c->num_cus * c->tune_primary_blocks), blk(PK_BLOCK);
+    // Alone on the chip the kernel fills it with eight workgroups per CU.  A launch that joins the previous launch's path kernel
+    // (one 16-wave workgroup per CU) finds room for four per CU; more than five only queue behind those and start when the
+    // items are nearly gone (bench.py, 256 steps: 16.1 Grays/s with 8 per CU, 16.6 with 5 or 6).
+    dim3 grid(c->tune_primary_grid > 0 ? c->tune_primary_grid : c->num_cus * (joins ? c->tune_primary_joined : c->tune_primary_blocks)), blk(PK_BLOCK);
     a.pk_ctr = c->d_pkctr + (size_t)slot * (PK_COUNTERS * 16);
     // consecutive items are the frames of one tile (identical packets: the second one finds its records in the scalar cache),
     // so long chunks pay for launches of many frames; short launches need small ones for balance (dragon80k: 16-frame launches
@@ -800,9 +804,9 @@ static int ensure_primary_hits(rt_context* c, const DCamera& dc, const rt_params
 // launch's path kernel rather than next to its primary pass.  Two primary passes side by side only slow each other down,
 // and the two path kernels after them then start together and drain together (bench.py --steps 20 on dragon80k:
 // 9.9 -> 11.8 Grays/s).
-static int launch_k_primary_pipelined(rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, hipStream_t pst) {
+static int launch_k_primary_pipelined(rt_context* c, const DCamera& dc, PathsArgs& a, uint32_t slot, hipStream_t pst, bool joins = false) {
     if (c->tune_stagger && c->prim_pending && c->prim_last != slot) HIPCHK(c, hipStreamWaitEvent(pst, c->prim_done[c->prim_last], 0));
-    launch_k_primary(c, dc, a, slot, false, pst);
+    launch_k_primary(c, dc, a, slot, false, pst, joins);
     HIPCHK(c, hipEventRecord(c->prim_done[slot], pst));
     c->prim_pending = true;
     c->prim_last = slot;
@@ -814,7 +818,8 @@ static int launch_k_primary_pipelined(rt_context* c, const DCamera& dc, PathsArg
 // (see rt_context::lane_stream) and overlaps with the previous launch's; the accumulate kernel, which carries the
 // frame-to-frame dependency, goes to the context's stream.
 static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params* p, uint32_t frame_base,
-                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined, bool followed = true) {
+                              uint32_t stride, uint32_t nframes, const float4* prev, float4* out, bool pipelined, bool followed = true,
+                              bool joins = false) {
     const bool fix = (p->flags & RT_FLAG_FIX_INVDIR) != 0;
     const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
     ahead_discard(c);  // this launch takes a staging slot of its own
@@ -846,7 +851,7 @@ static int launch_paths_batch(rt_context* c, const DCamera& dc, const rt_params*
     if (reuse && pipelined) HIPCHK(c, hipStreamWaitEvent(pst, c->phits_ready, 0));
     if (packets && (rc = ensure_rnodes(c)) != RT_OK) return rc;
     if (packets && pipelined) {
-        if ((rc = launch_k_primary_pipelined(c, dc, a, slot, pst)) != RT_OK) return rc;
+        if ((rc = launch_k_primary_pipelined(c, dc, a, slot, pst, joins)) != RT_OK) return rc;
     } else if (packets) {
         LaunchTimer lt(c, RT_K_PRIMARY);
         launch_k_primary(c, dc, a, slot, count, pst);
@@ -1059,6 +1064,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     if (const char* e = getenv("RT_TUNE_PRIMARY_CHUNK")) c->tune_primary_chunk = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_GRID")) c->tune_primary_grid = atoi(e);
     if (const char* e = getenv("RT_TUNE_PRIMARY_BLOCKS")) c->tune_primary_blocks = atoi(e);
+    if (const char* e = getenv("RT_TUNE_PRIMARY_JOINED")) c->tune_primary_joined = atoi(e);
     if (const char* e = getenv("RT_TUNE_SIGNED_SLABS")) c->tune_signed_slabs = atoi(e);
     if (const char* e = getenv("RT_TUNE_LAST_BLOCKS")) c->tune_last_blocks = atoi(e);
     if (const char* e = getenv("RT_BUILD_GEN")) c->build_gen = atoi(e) == 1 ? 1 : 2;
@@ -1077,6 +1083,7 @@ int rt_create(int device_id, rt_context** out_ctx) {
     c->tune_queue_blocks = clamp(c->tune_queue_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_last_blocks = clamp(c->tune_last_blocks, 1, PT_BLOCKS_PER_CU);
     c->tune_primary_blocks = clamp(c->tune_primary_blocks, 1, PK_BLOCKS_PER_CU);
+    c->tune_primary_joined = clamp(c->tune_primary_joined, 1, PK_BLOCKS_PER_CU);
     c->tune_primary_chunk = clamp(c->tune_primary_chunk, 0, 64);
     c->tune_primary_grid = clamp(c->tune_primary_grid, 0, 1 << 14);
     c->tune_frame_chunk = clamp(c->tune_frame_chunk, 1, 64);
@@ -1863,7 +1870,7 @@ int rt_render_device(rt_context* c, const rt_camera* cam, const rt_params* p, fl
         // 16 + 4 frames: 4.70 ms with one workgroup per CU for the remainder, 4.75 with two; 16, 64 steps: 4.43 -> 4.01,
         // 15.6 -> 15.1 ms with two for the last full launch)
         rc = launch_paths_batch(c, dc, p, p->frame_base + f * stride, stride, n, (const float4*)d_accum, (float4*)d_accum, true,
-                                f + n < p->frames || (f > 0 && 2u * n <= batch));
+                                f + n < p->frames || (f > 0 && 2u * n <= batch), f > 0);   // joins: its primary pass runs next to the previous launch's path kernel
         if (rc != RT_OK) return rc;
     }
     return RT_OK;
