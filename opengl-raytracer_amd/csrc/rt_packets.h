@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void k_rebase(const float4* nodes, float4* out
 // per-lane distances per entry.  The slab test, the triangle test (with the correctly rounded division) and their
 // instruction order are the compiler's own output for box_dist / tri_dist_flat, so results are bit-identical.
 // `nodes` are the launch's rebased records (k_rebase: box corners minus the common ray origin); the triangle test still
-// needs the origin.  Registers s36-s77 and v40-v61 are used by name.  Returns true when the stack would have outgrown PK_STACK.
+// needs the origin.  Registers s36-s73 and v40-v61 are used by name: with the compiler's own s0-s35, VCC and the reserved pairs that
+// is 80 SGPRs per wave.  A SIMD has 800 and the hardware sets 16 more per wave aside for the trap handler, so 80 is the most that
+// leaves room for 8 waves (a version that named registers up to s89 ran 7 per SIMD, and 3 instead of 4 next to a workgroup of
+// the path kernel).  Returns true when the stack would have outgrown PK_STACK.
 // The text comes in three pieces -- up to the arrival of an inner node's record, the two slab tests (which leave tNear
 // of child 1 / child 2 in v51 / v52 and tFar in v50 / v54, raytrace.glsl:117-120), and everything after them -- and PK_DEFINE_TRAVERSE makes one function per form of the slab tests.
 // The same for the triangle test (raytrace.glsl:79-110): with one origin for all rays of the launch, s = o - a,

@@ -854,6 +854,7 @@ def test_packet_that_outgrows_its_stack_hands_the_tile_back(pkg, oracle, gpu_ctx
     {"RT_TUNE_PRIMARY_CHUNK": "64"},                                 # longer than a short launch has items per wave
     {"RT_TUNE_SIGNED_SLABS": "0"},                                   # every packet through the general slab tests
     {"RT_TUNE_LAST_BLOCKS": "1", "RT_TUNE_QUEUE_BLOCKS": "2"},
+    {"RT_TUNE_PRIMARY_JOINED": "3", "RT_TUNE_PRIMARY_BLOCKS": "7"},   # other grids for the launch alone on the chip / next to a path kernel
 ])
 def test_packet_kernel_work_distribution_variants(pkg, oracle, scenes, env):
     """k_primary's waves pull chunks of work items from counters in memory; how many counters, how long the chunks and how
