@@ -399,30 +399,52 @@ __global__ __launch_bounds__(PK_BLOCK, PK_BLOCKS_PER_CU) void k_primary(DScene s
     // (dragon80k) to 8 % (teapot) slower end to end).
     const uint32_t nctr = pk_counters(gridDim.x), cid = blockIdx.x % nctr;
     uint32_t* const ctr = a.pk_ctr + cid * 16u;
-    uint32_t item = ((blockIdx.x / nctr * (PK_BLOCK / 64u) + (uint32_t)(tid >> 6)) * nctr + cid) * a.pk_chunk - 1u, left = a.pk_chunk + 1u;
-    for (;;) {
+    // The loop's own variables are wave-uniform and kept so by construction (the wave's number through readfirstlane): its
+    // branches are scalar ones, and the lanes of a wave cannot reach the grab below apart from each other.
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t item = ((blockIdx.x / nctr * (PK_BLOCK / 64u) + wave) * nctr + cid) * a.pk_chunk - 1u, left = a.pk_chunk + 1u;
+    // The items of a chunk are consecutive frames of one tile (or the last frames of one and the first of the next): the
+    // tile's pixels, its rays and their root-box test are worked out when the tile changes, not per item.  (The rays are
+    // traced for every frame all the same: only what is identical by construction is kept.)
+    uint32_t tq = 0u, f = 0u, cur_tile = 0xffffffffu;
+    bool fresh = true;   // the item's tile and frame come from a division (first item of a chunk), not from the previous item's
+    int gx = 0, gy = 0;
+    bool valid = false, in_root = false;
+    rt_vec3 o = rt_v3(0.0f, 0.0f, 0.0f), d = o, inv = o;
+    // every item is taken once; a wave that has gone round more often than there are items has lost its way and stops
+    for (uint32_t rounds = 0; rounds <= a.total_tiles; rounds++) {
         if (left == 1u) {
             uint32_t g = 0;
             if (lane == 0) g = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
             item = (g * nctr + cid) * a.pk_chunk;
             left = a.pk_chunk + 1u;
+            fresh = true;
         } else {
             item++;
         }
         left--;
         if (item >= a.total_tiles) break;   // the chunks after this one lie further out still
-        uint32_t f;
-        int gx, gy;
-        item_pixel(a, item, lane, f, gx, gy);
-        const bool valid = gx < cam.width && gy < cam.height;
-        rt_vec3 o, d, inv;
-        primary_ray(cam, gx, gy, o, d, inv);
+        if (fresh) {
+            tq = item / a.num_frames;
+            f = item - tq * a.num_frames;
+            fresh = false;
+        } else if (++f == a.num_frames) {
+            f = 0u;
+            tq++;
+        }
+        if (tq != cur_tile) {
+            cur_tile = tq;
+            tile_pixel(a, tq, lane, gx, gy);
+            valid = gx < cam.width && gy < cam.height;
+            primary_ray(cam, gx, gy, o, d, inv);
+            const float d0 = box_dist(o, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2]);
+            in_root = valid && d0 != RT_INF;
+        }
         float best = RT_INF;
         int best_id = -1;
         Counters cn = {0, 0, 0, 0, 0};
-        const float d0 = box_dist(o, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2]);
-        bool in = valid && d0 != RT_INF;   // does this lane take part in the current node?
+        bool in = in_root;   // does this lane take part in the current node?
         if (COUNT && valid) {
             cn.rays++;
             cn.box += in ? 2u : 1u;   // the reference evaluates the root box a second time to seed its stack

@@ -110,9 +110,8 @@ struct PathsArgs {
 // The frames of a launch share the camera: tile t of every frame is numbered before tile t+1 of any, so the waves that run
 // at one time walk the same part of the BVH.  Tiles are numbered strip by strip (PT_STRIP_W tile columns wide, row-major
 // inside), so that the tiles the chip works on at one time form a compact block of the image, not a full-width band.
-__device__ __forceinline__ void item_pixel(const PathsArgs& a, uint32_t item, int l, uint32_t& f, int& gx, int& gy) {
-    const uint32_t tq = item / a.num_frames;
-    f = item - tq * a.num_frames;
+// tile_pixel: the second half, from the tile's number tq = item / num_frames.
+__device__ __forceinline__ void tile_pixel(const PathsArgs& a, uint32_t tq, int l, int& gx, int& gy) {
     const int t = (int)tq;
     const int strip = t / a.strip_tiles, r = t - strip * a.strip_tiles;
     const int ty = r / PT_STRIP_W, tx = strip * PT_STRIP_W + r % PT_STRIP_W;
@@ -120,6 +119,11 @@ __device__ __forceinline__ void item_pixel(const PathsArgs& a, uint32_t item, in
     const int gty = a.stripe_period ? (ty / PT_STRIPE_TILES) * a.stripe_period + (ty % PT_STRIPE_TILES) + a.tile_y0 : ty + a.tile_y0;
     gx = tx * 8 + (l & 7);
     gy = gty * 8 + (l >> 3);
+}
+__device__ __forceinline__ void item_pixel(const PathsArgs& a, uint32_t item, int l, uint32_t& f, int& gx, int& gy) {
+    const uint32_t tq = item / a.num_frames;
+    f = item - tq * a.num_frames;
+    tile_pixel(a, tq, l, gx, gy);
 }
 
 __device__ __forceinline__ void flush_counters6(const Counters& cn, unsigned long long paths, unsigned long long* g) {
